@@ -1,0 +1,275 @@
+#!/usr/bin/env python3
+"""Benchmark of the env step hot path (BASELINE.json metric: env steps/s at 4096 envs/GPU).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one vector_step of every env of the rank's batch: ctrl map, frame_skip physics
+substeps, truncation, reward, observation, in-kernel auto-reset, plus the parameter
+regeneration + full reset every `regen_env_at_steps` steps -- all inside the timed region.
+Workload at N=1: BASELINE config 3 (drone + hanging load, 4096 envs, domain randomisation;
+train_RMA.py:66-75 settings); N>1 is config 4 (same per GPU, rank seeds 42+rank, one RCCL
+all-gather of the [T,N,...] trajectory fragment every T=1024 steps, inside the timed region).
+Actions are synthetic U[0,1) tensors already resident in HBM.  Prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+ALG_BYTES = {"load22": 309, "noload6": 181, "load23": 329}  # algorithmic bytes per env-step
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+
+
+def make_env(kind, n, seed, device, auto_reset=True):
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments import observation_wrappers as ow, rewards
+    if kind == "config3":
+        cfg = dict(base_config)
+        cfg.update(num_drones=n, random_params=True, param_difficulty=1, state_difficulty=0.2, max_steps=1024,
+                   regen_env_at_steps=1024, reward_fcn=rewards.distance_energy_reward, seed=seed, device=device,
+                   auto_reset=auto_reset)
+        return ow.LocalFrameRPYParamsEnv(cfg), "load22"
+    if kind == "config2":
+        from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
+        from mujoco_drone_amd import _lib as L
+        return SimpleDrone(num_drones=n, reference=[0, 0, 1], device=device, seed=seed, random_start=L.START_FIXED,
+                           auto_reset=auto_reset), "noload6"
+    raise ValueError(kind)
+
+
+def cpu_baseline(seconds_target=12.0):
+    """the oracle (C float64 port of the same step) on the host cores, config 3 at 4096 envs"""
+    import numpy as np
+    from oracle import oracle as orc
+    from mujoco_drone_amd import _lib as L
+    n = 4096
+    rng = np.random.default_rng(0)
+    center = np.array([1, 0.17, 7, 0.01, 1.2, 0.3]); width = np.array([0.1, 0.02, 1, 0.0025, 0.2, 0.05])
+    raw = center + rng.uniform(-1, 1, (n, 6)) * width
+    b = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameRPYParamsEnv"), L.REWARD_KINDS.index("distance_energy_reward"),
+                  0.01, 1, 1, [0, 0, 15, 0], 4.0, 1024)
+    b.qpos[:, 2] = 15.0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    acts = rng.uniform(0, 1, (8, n, 4))
+    b.step(acts[0], threads=cores)
+    t0 = time.perf_counter()
+    steps = 0
+    while time.perf_counter() - t0 < seconds_target:
+        for k in range(8):
+            b.step(acts[k], threads=cores)
+        steps += 8
+    dt = time.perf_counter() - t0
+    return {"value": n * steps / dt, "unit": "env steps/s", "cores": cores, "kind": "port",
+            "sample": "config 3 (load model, D=22 obs, distance_energy_reward), 4096 envs x %d steps, oracle/qd_oracle.c "
+                      "float64, OpenMP over envs; the reference's MuJoCo path is not runnable (mujoco absent)" % steps}
+
+
+def kernel_time_us(env, actions, samples=200):
+    """average duration of ONE step-kernel launch, HIP events on the launch stream around single launches
+    issued on an idle stream (minus the cost of an empty event pair)"""
+    import torch
+    s = torch.cuda.current_stream()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(samples)]
+    em = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(samples)]
+    step = env._dev.step
+    for i in range(samples):
+        torch.cuda.synchronize()
+        ev[i][0].record(s)
+        step(actions[i % actions.shape[0]])
+        ev[i][1].record(s)
+    torch.cuda.synchronize()
+    for i in range(samples):
+        torch.cuda.synchronize()
+        em[i][0].record(s)
+        em[i][1].record(s)
+    torch.cuda.synchronize()
+    import statistics
+    t = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
+    e = statistics.median(a.elapsed_time(b) for a, b in em) * 1e3
+    return max(t - e, 1e-3), t, e
+
+
+def stream_rate_us(env, actions, launches=4000):
+    """back-to-back launches, whole region between two events: per-launch period when the GPU queue is full"""
+    import torch
+    step = env._dev.step
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    P = actions.shape[0]
+    torch.cuda.synchronize()
+    a.record()
+    for i in range(launches):
+        step(actions[i % P])
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / launches
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8192)
+    ap.add_argument("--warmup", type=int, default=512)
+    ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
+    ap.add_argument("--config", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--fragment", type=int, default=1024, help="steps per all-gathered trajectory fragment (N>1)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from mujoco_drone_amd import parallel as par
+    rank, world, local = par.init_distributed()
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs a GPU"
+    torch.cuda.set_device(local)
+    device = "cuda:%d" % local
+    n, K, W = args.envs, args.steps, args.warmup
+
+    env, alg = make_env(args.config, n, par.shard_seed(42, rank), device)
+    step = env.vector_step_tensor if args.config == "config3" else env.step_tensor
+    if args.config == "config3":
+        env.vector_reset_tensor()
+        D = env._dev.D
+    else:
+        env.reset()
+        D = 6
+    lo, hi = (0.0, 1.0) if args.config == "config3" else (0.5, 1.0)
+    P = 64
+    g = torch.Generator(device=device); g.manual_seed(1000 + rank)
+    actions = lo + (hi - lo) * torch.rand((P, n, 4), generator=g, device=device, dtype=torch.float32)
+
+    T = min(args.fragment, K)
+    frag = gather = None
+    if world > 1:
+        frag = par.FragmentBuffers(T, n, D, device)
+        gather = par.FragmentGather(frag, world)
+
+    def run(k_steps, base=0):
+        for t in range(k_steps):
+            a = actions[(base + t) % P]
+            if frag is None:
+                step(a)
+            else:
+                tt = (base + t) % T
+                frag.actions[tt].copy_(a)
+                step(a, out=(frag.obs[tt], frag.rewards[tt], frag.truncated[tt]))
+                if tt == T - 1:
+                    gather(frag)
+
+    run(W)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(K, base=W)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    out = None
+    if rank == 0:
+        value = world * n * K / dt
+        out = {"metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
+               "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": ("BASELINE config 3: drone + hanging load, domain-randomised params, "
+                                       "LocalFrameRPYParamsEnv obs (D=22), distance_energy_reward, max_steps=1024, regen every "
+                                       "1024 steps, in-kernel auto-reset" if args.config == "config3" else
+                                       "BASELINE config 2: SimpleDrone (no load), fixed init, U[0.5,1) rotor actions, "
+                                       "2 substeps at 1 kHz") + ("; per-fragment RCCL all-gather of [T=%d,N,...] trajectories" % T
+                                                                if world > 1 else ""),
+                          "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 1 if args.config == "config3" else 2,
+                          "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world}}
+        # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
+        kus, raw_us, empty_us = kernel_time_us(env, actions)
+        period_us = stream_rate_us(env, actions)
+        bytes_per_launch = ALG_BYTES[alg] * n
+        achieved = bytes_per_launch / (kus * 1e-6) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get(args.config, {}).get(str(n))
+            except Exception:
+                traffic = None
+        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
+                           "kernel_us": kus, "event_pair_us": raw_us, "empty_event_pair_us": empty_us,
+                           "back_to_back_period_us": period_us, "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
+                           "env_steps_per_launch": n,
+                           "note": "4096 envs = 64 wavefronts on 1024 SIMDs: the launch is latency/occupancy-bound, "
+                                   "not HBM-bound (see DESIGN.md and the N sweep in `extras`)"}
+        if not args.no_extras and world == 1:
+            extras = {}
+            try:
+                sweep = []
+                for nn in (4096, 65536, 1048576):
+                    e2, alg2 = make_env(args.config, nn, 7, device)
+                    (e2.vector_reset_tensor() if args.config == "config3" else e2.reset())
+                    a2 = lo + (hi - lo) * torch.rand((4, nn, 4), device=device, dtype=torch.float32)
+                    for _ in range(20):
+                        e2._dev.step(a2[0])
+                    k2, _, _ = kernel_time_us(e2, a2, samples=40)
+                    p2 = stream_rate_us(e2, a2, launches=300)
+                    sweep.append({"envs": nn, "kernel_us": k2, "period_us": p2, "env_steps_per_s": nn / (p2 * 1e-6),
+                                  "alg_GBps": ALG_BYTES[alg2] * nn / (k2 * 1e-6) / 1e9,
+                                  "frac_hbm": ALG_BYTES[alg2] * nn / (k2 * 1e-6) / 1e9 / HBM_PEAK_GBS})
+                    del e2, a2
+                extras["env_count_sweep"] = sweep
+                # multi-step kernel (state in registers across T steps)
+                e3, _ = make_env(args.config, n, 11, device)
+                if args.config == "config3":
+                    e3.vector_reset_tensor()
+                    a3 = torch.rand((256, n, 4), device=device, dtype=torch.float32)
+                    e3._dev.rollout(a3)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(8):
+                        e3._dev.rollout(a3)
+                    torch.cuda.synchronize()
+                    extras["rollout_kernel_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
+                other = "config2" if args.config == "config3" else "config3"
+                e4, alg4 = make_env(other, n, 5, device)
+                (e4.vector_reset_tensor() if other == "config3" else e4.reset())
+                lo4, hi4 = (0.0, 1.0) if other == "config3" else (0.5, 1.0)
+                a4 = lo4 + (hi4 - lo4) * torch.rand((8, n, 4), device=device, dtype=torch.float32)
+                s4 = e4.vector_step_tensor if other == "config3" else e4.step_tensor
+                for i in range(200):
+                    s4(a4[i % 8])
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(2000):
+                    s4(a4[i % 8])
+                torch.cuda.synchronize()
+                extras[other + "_env_steps_per_s"] = 2000 * n / (time.perf_counter() - t1)
+            except Exception as ex:  # extras never invalidate the headline line
+                extras["error"] = repr(ex)
+            out["extras"] = extras
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline()
+        elif world > 1:
+            out["cpu_baseline"] = None
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+
+
+if __name__ == "__main__":
+    main()

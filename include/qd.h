@@ -1,0 +1,178 @@
+/*
+ * qd.h -- C ABI of the MI355X-native vectorised quadrotor(+hanging load) environment.
+ *
+ * The reference (TichyTech/mujoco-drone) has no FFI: its hot path is Python that calls
+ * the MuJoCo C library through the `mujoco` bindings.  This header is the boundary a
+ * maintainer binds instead (ctypes stub: INTEGRATION.md); every entry point names the
+ * reference interface it replaces (paths relative to the reference repo).
+ *
+ * Conventions
+ *   - plain C types only; no exceptions cross the boundary: every call returns a
+ *     qd_status (0 = ok, < 0 = error) and qd_last_error() gives the message of the last
+ *     failure on the calling thread;
+ *   - all array arguments are DEVICE pointers owned by the caller (e.g. PyTorch-ROCm
+ *     tensors' data_ptr()) unless the name ends in _host; row-major; float32 unless
+ *     stated otherwise;
+ *   - `stream` is a hipStream_t passed as void* (NULL = the null stream); calls are
+ *     asynchronous with respect to the host and ordered on that stream;
+ *   - one qd_env is not thread-safe; distinct handles are independent;
+ *   - simulator state lives in a caller-allocated arena of qd_arena_bytes() bytes
+ *     (struct-of-float4-groups), so the library never allocates device
+ *     memory and never synchronises the device.
+ */
+#ifndef QD_H
+#define QD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define QD_VERSION 1
+
+typedef struct qd_env qd_env;
+
+typedef enum qd_status {
+  QD_OK = 0,
+  QD_ERR_INVALID = -1,      /* bad argument / configuration */
+  QD_ERR_SHAPE = -2,        /* "Action dimension mismatch" (mujoco_env_custom.py:200-201) */
+  QD_ERR_UNSUPPORTED = -3,  /* e.g. the observation variant that raises NameError in the reference */
+  QD_ERR_HIP = -4,          /* a HIP runtime call failed */
+  QD_ERR_ARENA = -5,        /* arena too small or misaligned */
+  QD_ERR_INDEX = -6         /* env index out of range (AssertionError in BaseDroneEnv.py:338) */
+} qd_status;
+
+enum { QD_MODEL_NOLOAD = 0, QD_MODEL_LOAD = 1 };            /* config['pendulum'] */
+enum { QD_CTRL_DIRECT = 0,  /* ctrl = action            (SimpleDrone.py:55)      */
+       QD_CTRL_AFFINE = 1   /* ctrl = 0.1 + 0.9*action  (BaseDroneEnv.py:269)    */ };
+enum { QD_TERM_DEFAULT = 0, /* default_termination_fcn  (BaseDroneEnv.py:12-16)  */
+       QD_TERM_SIMPLE = 1   /* |pos - ref| > 0.5        (SimpleDrone.py:57)      */ };
+
+enum { QD_START_FIXED = 0,  /* random_start_pos = False   (BaseDroneEnv.py:245-256) */
+       QD_START_RANDOM = 1, /* random_start_pos = True    (BaseDroneEnv.py:220-244) */
+       QD_START_SIMPLE = 2  /* SimpleDrone.reset_model    (SimpleDrone.py:63-72)    */ };
+
+/* observation variants: BaseDroneEnv._get_obs and the classes of observation_wrappers.py, in file order */
+enum {
+  QD_OBS_RAW = 0, QD_OBS_GLOBAL_RPY, QD_OBS_LOCAL_PRY, QD_OBS_FULLSTATE, QD_OBS_FULLSTATE_ZVEC, QD_OBS_PRY_ACC,
+  QD_OBS_PRY_PARAMS, QD_OBS_PRY_ACC_PARAMS, QD_OBS_RPY_PARAMS, QD_OBS_RPY_FAKEPARAMS, QD_OBS_LOCAL_RPY,
+  QD_OBS_PRY_ACC_NOPEND, QD_OBS_PRY_ACC_PARAMS_NOPEND /* unsupported: raises in the reference */,
+  QD_OBS_RM_PARAMS, QD_OBS_ZVEC, QD_OBS_SIMPLE /* SimpleDrone._get_obs */, QD_OBS_COUNT
+};
+/* reward functions of rewards.py in file order, then SimpleDrone.step's */
+enum {
+  QD_REW_DEFAULT = 0, QD_REW_DISTANCE, QD_REW_DISTANCE_ENERGY, QD_REW_PEND_ANGLE, QD_REW_PEND_ANGLE2,
+  QD_REW_PEND_ANGLE3, QD_REW_PEND_EN, QD_REW_PEND_EN2, QD_REW_PEND_EN3, QD_REW_PEND_EN4,
+  QD_REW_DISTANCE_TIME_ENERGY, QD_REW_REWARD_1, QD_REW_PEND_DIST, QD_REW_PEND_DIST_HEADING, QD_REW_REWARD_2,
+  QD_REW_REWARD_2_PENERGY, QD_REW_REWARD_3, QD_REW_SIMPLE, QD_REW_COUNT
+};
+/* attitude conversions of transformation.py */
+enum { QD_TF_QUAT2RPY = 0, QD_TF_RPY2QUAT, QD_TF_QUAT2DCM, QD_TF_DCM2QUAT, QD_TF_PENDRP2QUAT };
+
+/* Mirrors the keys BaseDroneEnv.__init__ reads (BaseDroneEnv.py:60-106); variances are
+ * already multiplied by state_difficulty as at BaseDroneEnv.py:101-106. */
+typedef struct qd_config {
+  int32_t  num_envs;            /* config['num_drones'] */
+  int32_t  model;               /* QD_MODEL_* */
+  int32_t  obs_kind, reward_kind;
+  int32_t  frame_skip;          /* config['skip_steps']; SimpleDrone uses 2 */
+  int32_t  max_steps;
+  int32_t  ctrl_map, term_kind;
+  int32_t  random_start;        /* QD_START_*: config['random_start_pos'] */
+  int32_t  random_params;       /* config['random_params'] */
+  int32_t  auto_reset;          /* extension: re-sample truncated envs inside the step kernel */
+  int32_t  per_env_reference;   /* extension: reference[N,4] lives in the arena (moving waypoints) */
+  double   timestep;            /* 1 / config['frequency'] */
+  double   max_distance;
+  double   reference[4];        /* x, y, z, yaw */
+  double   start_pos[4];
+  double   max_pos_offset;
+  double   angle_var[2], vel_var[3], ang_vel_var[3], pend_rp_var[2], pend_vel_var[2];
+  double   param_center[6], param_width[6]; /* mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass */
+  double   param_difficulty;
+  uint64_t seed;
+} qd_config;
+
+const char* qd_last_error(void);
+int         qd_version(void);
+
+/* observation length D for (variant, model): observation_space.shape[0] as actually emitted */
+int    qd_obs_dim(int obs_kind, int model);
+/* length of BaseDroneEnv.get_drone_states() rows: 33 with the load, 29 without */
+int    qd_state_dim(int model);
+size_t qd_arena_bytes(int num_envs);
+
+/* BaseDroneEnv.__init__ / SimpleDrone.__init__: bind a configuration to a caller-owned,
+ * 256-byte aligned device arena.  The arena content is initialised by qd_init. */
+int qd_create(const qd_config* cfg, void* arena, size_t arena_bytes, qd_env** out);
+int qd_destroy(qd_env* env);
+/* generate_drone_params + make_sim + mjcf_to_mjmodel + MjData() (BaseDroneEnv.py:117,125;
+ * mujoco_env_custom.py:189): parameters (randomised on device if random_params), derived model
+ * constants, spawn-grid qpos0 (env_gen.py:116-124), zero velocities / activations / sensor. */
+int qd_init(qd_env* env, void* stream);
+
+/* mj_resetData (mujoco_vecenv.py:393-394, reached through env.reset()): qpos0, zero velocities,
+ * activations and sensor data.  Episode counters and references are kept. */
+int qd_reset_data(qd_env* env, void* stream);
+
+/* env.reference = [...] (evaluation.py:48,66) */
+int qd_set_reference(qd_env* env, const double ref_host[4]);
+/* extension for per-env moving waypoints (BASELINE config 5): ref[N,4] */
+int qd_set_reference_per_env(qd_env* env, const float* ref, void* stream);
+
+/* reset_model(regen=True) first half (BaseDroneEnv.py:298-310): new parameters for every env,
+ * new model constants, fresh MjData (activations and sensor zeroed). */
+int qd_randomize_params(qd_env* env, void* stream);
+/* explicit parameters, float64 raw[N,6] (what env.drone_params holds) */
+int qd_set_params(qd_env* env, const double* raw, void* stream);
+int qd_get_params(qd_env* env, double* raw, void* stream);
+
+/* reset_model second half / vector_reset (BaseDroneEnv.py:312-332): sample_state for every env
+ * (mask == NULL) or for envs with mask[i] != 0, num_steps = 0, mj_forward (sensor refresh);
+ * activations persist (reference quirk).  obs (nullable) receives _get_obs() for ALL envs. */
+int qd_reset(qd_env* env, const uint8_t* mask, float* obs, void* stream);
+/* reset_at(index) (BaseDroneEnv.py:334-351) */
+int qd_reset_at(qd_env* env, int index, void* stream);
+
+/* set_state(qpos, qvel) (mujoco_vecenv.py:396-402): qpos[N,nq], qvel[N,nv], then mj_forward.
+ * act (nullable, [N,4]) additionally overwrites the activations (data.act[:] = ...). */
+int qd_set_state(qd_env* env, const float* qpos, const float* qvel, const float* act, void* stream);
+/* data.qpos / data.qvel / data.act / data.sensordata / num_steps; any pointer may be NULL */
+int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* sensordata, int32_t* num_steps,
+                 void* stream);
+
+/* vector_step (BaseDroneEnv.py:259-294) / SimpleDrone.step (SimpleDrone.py:54-61) for all envs:
+ * ctrl map, frame_skip x mj_step, num_steps += 1, truncation, reward, observation.
+ * n_action_values must equal 4*num_envs, else QD_ERR_SHAPE.  actions[N,4], obs[N,D],
+ * reward[N], truncated[N] (uint8).  With auto_reset, truncated envs are re-sampled in the same
+ * launch and their obs row is the first observation of the new episode. */
+int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
+            uint8_t* truncated, void* stream);
+/* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
+ * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */
+int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated,
+               void* stream);
+
+/* _get_obs() on the current simulator state, obs[N,D] */
+int qd_observe(qd_env* env, float* obs, void* stream);
+/* get_drone_states() (BaseDroneEnv.py:357-380): states[N, qd_state_dim(model)] */
+int qd_drone_states(qd_env* env, float* states, void* stream);
+
+/* Stateless evaluation of the reference's pure functions on caller-provided state vectors
+ * (rows of get_drone_states()); used by the Python mirrors of rewards.py /
+ * observation_wrappers.py and by the parity tests.  ns = 33 or 29. */
+int qd_eval_obs(int obs_kind, int ns, const float* states, const double ref_host[4], float* obs, int n,
+                void* stream);
+int qd_eval_reward(int reward_kind, int ns, const float* states, const float* actions, const int32_t* num_steps,
+                   const double ref_host[4], double max_distance, float* reward, int n, void* stream);
+int qd_eval_truncated(int ns, const float* states, const int32_t* num_steps, const double ref_host[4],
+                      double max_distance, int max_steps, uint8_t* truncated, int n, void* stream);
+/* transformation.py:5-29 on n rows */
+int qd_transform(int which, const float* in, float* out, int n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

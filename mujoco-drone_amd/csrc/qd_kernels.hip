@@ -1,0 +1,834 @@
+// qd_kernels.hip -- gfx950 kernels and the C ABI (include/qd.h) of the vectorised
+// quadrotor(+load) environment.  One env per lane, 64-wide wavefronts.
+//
+// HBM layout ("arena", caller-owned): NUM_GROUPS planes of float4[npad], i.e. every
+// lane moves its state with 16-byte loads/stores and a wavefront touches 1 KiB of
+// consecutive memory per instruction (the widest coalesced access on CDNA4), followed by
+// 6 planes of double[npad] holding the raw float64 model parameters:
+//   POS  (px,py,pz,th1)   QUAT (qw,qx,qy,qz)   VEL (vx,vy,vz,th2)   ANG (wx,wy,wz,thd1)
+//   ACT  (a0..a3)         AUX  (thd2, num_steps:i32, episode:u32, -)
+//   ACC  (accelerometer xyz, -)                 M0..M3 derived model constants (qd_model.h)
+//   P0   (mass, arm_len, motor_force, motor_tau) P1 (pendulum_len, weight_mass, -, -)
+//   REF  (x,y,z,yaw) per-env reference (only read when per_env_reference is set)
+// Observations are produced row-major [N,D] (what the policy network consumes); a
+// wavefront's 64 rows are one contiguous 64*D*4-byte span, so rows are staged through LDS
+// and written back with full-width coalesced stores.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "../../include/qd.h"
+#include "qd_dynamics.h"
+#include "qd_math.h"
+#include "qd_model.h"
+#include "qd_obsrew.h"
+#include "qd_rng.h"
+
+namespace qd {
+
+enum Group {
+  G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_P0, G_P1, G_REF, NUM_GROUPS
+};
+constexpr int RAW_PLANES = 6;
+constexpr int PAD = 256;
+
+struct KArgs {
+  float4* g;
+  double* raw;
+  int npad, n;
+  float ref[4];
+  int per_env_ref;
+  float h;
+  int frame_skip, ctrl_map, obs_kind, reward_kind, term_kind;
+  float max_distance;
+  int max_steps, auto_reset, D;
+  unsigned long long seed;
+  SampleCfg sc;
+};
+
+struct EnvRegs {  // everything one lane keeps in registers for one env
+  State<float> s;
+  Model<float> M;
+  V3<float> acc;
+  float par[6];
+  float ref[4];
+  int num_steps;
+  uint32_t episode;
+  float aux_w;
+};
+
+template <bool LOAD>
+__device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
+  const float4* g = a.g;
+  const int np = a.npad;
+  const float4 pos = g[G_POS * np + i], qt = g[G_QUAT * np + i], vel = g[G_VEL * np + i], ang = g[G_ANG * np + i];
+  const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i], acc = g[G_ACC * np + i];
+  const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i];
+  const float4 p0 = g[G_P0 * np + i], p1 = g[G_P1 * np + i];
+  e.s.px = pos.x; e.s.py = pos.y; e.s.pz = pos.z; e.s.th1 = pos.w;
+  e.s.qw = qt.x; e.s.qx = qt.y; e.s.qy = qt.z; e.s.qz = qt.w;
+  e.s.vx = vel.x; e.s.vy = vel.y; e.s.vz = vel.z; e.s.th2 = vel.w;
+  e.s.wx = ang.x; e.s.wy = ang.y; e.s.wz = ang.z; e.s.thd1 = ang.w;
+  e.s.a0 = act.x; e.s.a1 = act.y; e.s.a2 = act.z; e.s.a3 = act.w;
+  e.s.thd2 = aux.x; e.num_steps = __float_as_int(aux.y); e.episode = __float_as_uint(aux.z); e.aux_w = aux.w;
+  e.acc = mk<float>(acc.x, acc.y, acc.z);
+  e.M.m0 = m0.x; e.M.c0z = m0.y; e.M.I0x = m0.z; e.M.I0y = m0.w;
+  e.M.I0z = m1.x; e.M.rot = m1.y; e.M.gearF = m1.z; e.M.gearT = m1.w;
+  e.M.inv_tau = m2.x; e.M.m2 = m2.y; e.M.lc = m2.z; e.M.I2t = m2.w;
+  e.M.I2a = 0.f; e.M.pad0 = e.M.pad1 = e.M.pad2 = 0.f;
+  if (LOAD) e.M.I2a = g[G_M3 * np + i].x;
+  e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
+  if (a.per_env_ref) {
+    const float4 r = g[G_REF * np + i];
+    e.ref[0] = r.x; e.ref[1] = r.y; e.ref[2] = r.z; e.ref[3] = r.w;
+  } else {
+    e.ref[0] = a.ref[0]; e.ref[1] = a.ref[1]; e.ref[2] = a.ref[2]; e.ref[3] = a.ref[3];
+  }
+}
+
+__device__ __forceinline__ void store_env(const KArgs& a, int i, const EnvRegs& e) {
+  float4* g = a.g;
+  const int np = a.npad;
+  g[G_POS * np + i] = make_float4(e.s.px, e.s.py, e.s.pz, e.s.th1);
+  g[G_QUAT * np + i] = make_float4(e.s.qw, e.s.qx, e.s.qy, e.s.qz);
+  g[G_VEL * np + i] = make_float4(e.s.vx, e.s.vy, e.s.vz, e.s.th2);
+  g[G_ANG * np + i] = make_float4(e.s.wx, e.s.wy, e.s.wz, e.s.thd1);
+  g[G_ACT * np + i] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
+  g[G_AUX * np + i] = make_float4(e.s.thd2, __int_as_float(e.num_steps), __uint_as_float(e.episode), e.aux_w);
+  g[G_ACC * np + i] = make_float4(e.acc.x, e.acc.y, e.acc.z, 0.f);
+}
+
+// accelerometer refresh = the part of mj_forward the reference observes after set_state
+template <bool LOAD>
+__device__ __forceinline__ void refresh_sensor(const KArgs& a, EnvRegs& e) {
+  Accel<float> ex, im;
+  forward<float, LOAD>(e.M, e.s, a.h, &ex, &im, &e.acc);
+}
+
+// sample_state for this lane's env, episode counter advanced
+template <bool LOAD>
+__device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e) {
+  if (a.sc.random_start == QD_START_SIMPLE) {
+    sample_simple(a.sc, a.seed, (uint32_t)i, (uint32_t)a.n, e.episode, e.s);
+  } else {
+    float z[16], u[2];
+    sample_draws(a.seed, (uint32_t)i, e.episode, z, u);
+    sample_state<LOAD>(a.sc, z, u, e.s);
+  }
+  e.episode += 1u;
+  e.num_steps = 0;
+  refresh_sensor<LOAD>(a, e);
+}
+
+// ---- observation rows ---------------------------------------------------------------
+// Each lane produces D floats.  The block's rows are first written to LDS at
+// [lane][k] (row-major, i.e. exactly the image of the global span) and then copied
+// out with consecutive lanes writing consecutive dwords.
+constexpr int OBS_LDS_FLOATS = 64 * QD_MAX_OBS;
+
+template <int NS, int KIND>
+__device__ __forceinline__ void obs_to_lds(const float* sv, const float ref[4], float* row) {
+  float o[QD_MAX_OBS];
+  const int n = observe<float, NS, KIND>(sv, ref, o);
+#pragma unroll
+  for (int k = 0; k < QD_MAX_OBS; k++)
+    if (k < n) row[k] = o[k];
+}
+
+template <bool LOAD>
+__device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, const float* sv, float* row) {
+  constexpr int NS = LOAD ? 33 : 29;
+  if (a.obs_kind == OBS_SIMPLE) {
+    float o[6];
+    simple_obs<float>(e.s, o);
+#pragma unroll
+    for (int k = 0; k < 6; k++) row[k] = o[k];
+    return;
+  }
+#define QD_CALL(K) obs_to_lds<NS, K>(sv, e.ref, row)
+  QD_OBS_DISPATCH(a.obs_kind, QD_CALL)
+#undef QD_CALL
+}
+
+// copy the wave's staged rows (64 x D floats, contiguous in LDS and in global memory)
+__device__ __forceinline__ void flush_obs(const float* tile, float* dst, int rows, int D) {
+  const int lane = threadIdx.x & 63;
+  const int total = rows * D;
+  for (int j = lane; j < total; j += 64) dst[j] = tile[j];
+}
+
+// ---- one full env step for the lane's env (everything after the state is in registers) ----
+template <bool LOAD>
+__device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, float4 action, float* obs_row, float* rew,
+                                         uint8_t* trunc) {
+  constexpr int NS = LOAD ? 33 : 29;
+  float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
+  if (a.ctrl_map == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+  c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
+  for (int k = 0; k < a.frame_skip; k++) e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  e.num_steps += 1;
+  float sv[33];
+  const float act4[4] = {action.x, action.y, action.z, action.w};
+  bool tr;
+  float r;
+  if (a.term_kind == QD_TERM_SIMPLE) {
+    // SimpleDrone.step: terminated = |pos - ref| > 0.5, reward = 0.1 - |pos - ref| (SimpleDrone.py:57-60)
+    const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    tr = d > 0.5f;
+    r = 0.1f - d;
+    sv[0] = e.s.px; sv[1] = e.s.py; sv[2] = e.s.pz;
+  } else {
+    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+    tr = truncated<float>(sv, e.ref, e.num_steps, a.max_distance, a.max_steps);
+    r = reward<float>(a.reward_kind, sv, act4, e.num_steps, e.ref, a.max_distance);
+  }
+  if (a.auto_reset && tr) {
+    resample<LOAD>(a, i, e);
+    if (a.term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+  }
+  *rew = r;
+  *trunc = tr ? 1 : 0;
+  write_obs_row<LOAD>(a, e, sv, obs_row);
+  (void)NS;
+}
+
+template <bool LOAD, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+                                                float* __restrict__ reward, uint8_t* __restrict__ trunc) {
+  __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* wtile = tile + wave * OBS_LDS_FLOATS;
+  const int wave_base = i - lane;  // first env of this wavefront
+  if (i < a.n) {
+    EnvRegs e;
+    load_env<LOAD>(a, i, e);
+    const float4 action = reinterpret_cast<const float4*>(actions)[i];
+    float r;
+    uint8_t t;
+    env_step<LOAD>(a, i, e, action, wtile + lane * a.D, &r, &t);
+    store_env(a, i, e);
+    reward[i] = r;
+    trunc[i] = t;
+  }
+  // wave-local staging: the LDS tile is private to the wavefront, so no block barrier is needed
+  __builtin_amdgcn_wave_barrier();
+  if (wave_base < a.n) {
+    const int rows = min(64, a.n - wave_base);
+    flush_obs(wtile, obs + (size_t)wave_base * a.D, rows, a.D);
+  }
+}
+
+// T steps per launch, state in registers between steps
+template <bool LOAD, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* __restrict__ actions,
+                                                   float* __restrict__ obs, float* __restrict__ reward,
+                                                   uint8_t* __restrict__ trunc) {
+  __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* wtile = tile + wave * OBS_LDS_FLOATS;
+  const int wave_base = i - lane;
+  const bool live = i < a.n;
+  EnvRegs e;
+  if (live) load_env<LOAD>(a, i, e);
+  for (int t = 0; t < T; t++) {
+    if (live) {
+      const float4 action = reinterpret_cast<const float4*>(actions)[(size_t)t * a.n + i];
+      float r;
+      uint8_t tr;
+      env_step<LOAD>(a, i, e, action, wtile + lane * a.D, &r, &tr);
+      reward[(size_t)t * a.n + i] = r;
+      trunc[(size_t)t * a.n + i] = tr;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (wave_base < a.n) {
+      const int rows = min(64, a.n - wave_base);
+      flush_obs(wtile, obs + ((size_t)t * a.n + wave_base) * a.D, rows, a.D);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (live) store_env(a, i, e);
+}
+
+// _get_obs() of the current state for every env (also used after reset / regen)
+template <bool LOAD, int BLOCK>
+__global__ __launch_bounds__(BLOCK) void k_observe(KArgs a, float* __restrict__ obs) {
+  __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
+  const int i = blockIdx.x * BLOCK + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  float* wtile = tile + wave * OBS_LDS_FLOATS;
+  const int wave_base = i - lane;
+  if (i < a.n) {
+    EnvRegs e;
+    load_env<LOAD>(a, i, e);
+    float sv[33];
+    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+    write_obs_row<LOAD>(a, e, sv, wtile + lane * a.D);
+  }
+  __builtin_amdgcn_wave_barrier();
+  if (wave_base < a.n) flush_obs(wtile, obs + (size_t)wave_base * a.D, min(64, a.n - wave_base), a.D);
+}
+
+// reset_model / reset_at: mask == nullptr && index < 0 -> all envs
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_reset(KArgs a, const uint8_t* __restrict__ mask, int index) {
+  int i = blockIdx.x * 64 + threadIdx.x;
+  if (index >= 0) i = (i == 0) ? index : a.n;
+  if (i >= a.n) return;
+  if (mask && !mask[i]) return;
+  EnvRegs e;
+  load_env<LOAD>(a, i, e);
+  resample<LOAD>(a, i, e);
+  store_env(a, i, e);
+}
+
+// generate_drone_params / explicit params -> raw planes, float32 copies, derived constants
+__global__ __launch_bounds__(64) void k_params(KArgs a, ParamCfg pc, uint32_t regen, const double* __restrict__ explicit_raw,
+                                               int fresh_data) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  double raw[6];
+  if (explicit_raw) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) raw[k] = explicit_raw[(size_t)i * 6 + k];
+  } else {
+    gen_params(pc, a.seed, (uint32_t)i, regen, raw);
+  }
+#pragma unroll
+  for (int k = 0; k < 6; k++) a.raw[(size_t)k * a.npad + i] = raw[k];
+  bool load;
+  const Model<double> M = derive_model(raw, &load);
+  float4* g = a.g;
+  const int np = a.npad;
+  g[G_M0 * np + i] = make_float4((float)M.m0, (float)M.c0z, (float)M.I0x, (float)M.I0y);
+  g[G_M1 * np + i] = make_float4((float)M.I0z, (float)M.rot, (float)M.gearF, (float)M.gearT);
+  g[G_M2 * np + i] = make_float4((float)M.inv_tau, (float)M.m2, (float)M.lc, (float)M.I2t);
+  g[G_M3 * np + i] = make_float4((float)M.I2a, 0.f, 0.f, 0.f);
+  g[G_P0 * np + i] = make_float4((float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]);
+  g[G_P1 * np + i] = make_float4((float)raw[4], (float)raw[5], 0.f, 0.f);
+  if (fresh_data) {  // a new MjData: activations and sensordata start at zero
+    g[G_ACT * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    g[G_ACC * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+// MjData() / mj_resetData: qpos0 from the spawn grid (env_gen.py:116-124), everything else zero.
+// full != 0 additionally clears the per-env episode counters and per-env references (construction).
+__global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  const int sz = (int)ceil(sqrt((double)a.n));
+  const double x = round5(((double)(i % sz) - (sz - 1) * 0.5) * 0.5);
+  const double y = round5(((double)(i / sz) - (sz - 1) * 0.5) * 0.5);
+  float4* g = a.g;
+  const int np = a.npad;
+  g[G_POS * np + i] = make_float4((float)x, (float)y, 0.15f, 0.f);
+  g[G_QUAT * np + i] = make_float4(1.f, 0.f, 0.f, 0.f);
+  g[G_VEL * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  g[G_ANG * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  g[G_ACT * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  g[G_ACC * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (full) {
+    g[G_AUX * np + i] = make_float4(0.f, __int_as_float(0), __uint_as_float(0u), 0.f);
+    g[G_REF * np + i] = make_float4(a.ref[0], a.ref[1], a.ref[2], a.ref[3]);
+  } else {
+    float4 aux = g[G_AUX * np + i];
+    aux.x = 0.f;
+    g[G_AUX * np + i] = aux;
+  }
+}
+
+__global__ __launch_bounds__(64) void k_get_params(KArgs a, double* __restrict__ out) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+#pragma unroll
+  for (int k = 0; k < 6; k++) out[(size_t)i * 6 + k] = a.raw[(size_t)k * a.npad + i];
+}
+
+__global__ __launch_bounds__(64) void k_set_ref(KArgs a, const float* __restrict__ ref) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  a.g[G_REF * a.npad + i] = reinterpret_cast<const float4*>(ref)[i];
+}
+
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_set_state(KArgs a, const float* __restrict__ qpos, const float* __restrict__ qvel,
+                                                  const float* __restrict__ act) {
+  constexpr int NQ = LOAD ? 9 : 7, NV = LOAD ? 8 : 6;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  EnvRegs e;
+  load_env<LOAD>(a, i, e);
+  const float* qp = qpos + (size_t)i * NQ;
+  const float* qv = qvel + (size_t)i * NV;
+  e.s.px = qp[0]; e.s.py = qp[1]; e.s.pz = qp[2]; e.s.qw = qp[3]; e.s.qx = qp[4]; e.s.qy = qp[5]; e.s.qz = qp[6];
+  e.s.vx = qv[0]; e.s.vy = qv[1]; e.s.vz = qv[2]; e.s.wx = qv[3]; e.s.wy = qv[4]; e.s.wz = qv[5];
+  if (LOAD) { e.s.th1 = qp[7]; e.s.th2 = qp[8]; e.s.thd1 = qv[6]; e.s.thd2 = qv[7]; }
+  if (act) { e.s.a0 = act[4 * i]; e.s.a1 = act[4 * i + 1]; e.s.a2 = act[4 * i + 2]; e.s.a3 = act[4 * i + 3]; }
+  refresh_sensor<LOAD>(a, e);
+  store_env(a, i, e);
+}
+
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_get_state(KArgs a, float* __restrict__ qpos, float* __restrict__ qvel,
+                                                  float* __restrict__ act, float* __restrict__ sens,
+                                                  int32_t* __restrict__ num_steps) {
+  constexpr int NQ = LOAD ? 9 : 7, NV = LOAD ? 8 : 6;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  EnvRegs e;
+  load_env<LOAD>(a, i, e);
+  if (qpos) {
+    float* qp = qpos + (size_t)i * NQ;
+    qp[0] = e.s.px; qp[1] = e.s.py; qp[2] = e.s.pz; qp[3] = e.s.qw; qp[4] = e.s.qx; qp[5] = e.s.qy; qp[6] = e.s.qz;
+    if (LOAD) { qp[7] = e.s.th1; qp[8] = e.s.th2; }
+  }
+  if (qvel) {
+    float* qv = qvel + (size_t)i * NV;
+    qv[0] = e.s.vx; qv[1] = e.s.vy; qv[2] = e.s.vz; qv[3] = e.s.wx; qv[4] = e.s.wy; qv[5] = e.s.wz;
+    if (LOAD) { qv[6] = e.s.thd1; qv[7] = e.s.thd2; }
+  }
+  if (act) { act[4 * i] = e.s.a0; act[4 * i + 1] = e.s.a1; act[4 * i + 2] = e.s.a2; act[4 * i + 3] = e.s.a3; }
+  if (sens) { sens[3 * i] = e.acc.x; sens[3 * i + 1] = e.acc.y; sens[3 * i + 2] = e.acc.z; }
+  if (num_steps) num_steps[i] = e.num_steps;
+}
+
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_drone_states(KArgs a, float* __restrict__ out) {
+  constexpr int NS = LOAD ? 33 : 29;
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  EnvRegs e;
+  load_env<LOAD>(a, i, e);
+  float sv[33];
+  drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+#pragma unroll
+  for (int k = 0; k < NS; k++) out[(size_t)i * NS + k] = sv[k];
+}
+
+// ---- stateless evaluation of the reference's pure functions ----------------------------
+struct EvalArgs {
+  float ref[4];
+  float max_distance;
+  int max_steps, kind, n, D;
+};
+
+template <int NS>
+__global__ __launch_bounds__(64) void k_eval_obs(EvalArgs a, const float* __restrict__ states, float* __restrict__ obs) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  float sv[33];
+#pragma unroll
+  for (int k = 0; k < NS; k++) sv[k] = states[(size_t)i * NS + k];
+  float* row = obs + (size_t)i * a.D;
+#define QD_CALL(K) obs_to_lds<NS, K>(sv, a.ref, row)
+  QD_OBS_DISPATCH(a.kind, QD_CALL)
+#undef QD_CALL
+}
+
+template <int NS>
+__global__ __launch_bounds__(64) void k_eval_reward(EvalArgs a, const float* __restrict__ states,
+                                                    const float* __restrict__ actions, const int32_t* __restrict__ ks,
+                                                    float* __restrict__ out, uint8_t* __restrict__ tr) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  float sv[33];
+#pragma unroll
+  for (int k = 0; k < 33; k++) sv[k] = (k < NS) ? states[(size_t)i * NS + k] : 0.f;
+  const int k = ks ? ks[i] : 0;
+  if (out) {
+    const float act4[4] = {actions[4 * i], actions[4 * i + 1], actions[4 * i + 2], actions[4 * i + 3]};
+    out[i] = reward<float>(a.kind, sv, act4, k, a.ref, a.max_distance);
+  }
+  if (tr) tr[i] = truncated<float>(sv, a.ref, k, a.max_distance, a.max_steps) ? 1 : 0;
+}
+
+__global__ __launch_bounds__(64) void k_transform(int which, const float* __restrict__ in, float* __restrict__ out, int n) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= n) return;
+  if (which == QD_TF_QUAT2RPY || which == QD_TF_QUAT2DCM) {
+    const float* q = in + 4 * i;
+    const float qn = 1.f / sqrtf(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+    const float w = q[0] * qn, x = q[1] * qn, y = q[2] * qn, z = q[3] * qn;
+    if (which == QD_TF_QUAT2RPY) {
+      quat2rpy(w, x, y, z, out + 3 * i, out + 3 * i + 1, out + 3 * i + 2);
+    } else {
+      const M3<float> R = quat2mat(w, x, y, z);
+      float* o = out + 9 * i;
+      o[0] = R.m00; o[1] = R.m01; o[2] = R.m02; o[3] = R.m10; o[4] = R.m11; o[5] = R.m12; o[6] = R.m20; o[7] = R.m21; o[8] = R.m22;
+    }
+  } else if (which == QD_TF_RPY2QUAT || which == QD_TF_PENDRP2QUAT) {
+    float* o = out + 4 * i;
+    if (which == QD_TF_RPY2QUAT) {
+      const float* r = in + 3 * i;
+      float sr, cr, sp, cp, sy, cy;
+      qsincos(0.5f * r[0], &sr, &cr); qsincos(0.5f * r[1], &sp, &cp); qsincos(0.5f * r[2], &sy, &cy);
+      o[0] = cr * cp * cy + sr * sp * sy; o[1] = sr * cp * cy - cr * sp * sy;
+      o[2] = cr * sp * cy + sr * cp * sy; o[3] = cr * cp * sy - sr * sp * cy;
+    } else {
+      const float* r = in + 2 * i;  // R = Rx(a) Ry(b) (transformation.py:27-29)
+      float sa, ca, sb, cb;
+      qsincos(0.5f * r[0], &sa, &ca); qsincos(0.5f * r[1], &sb, &cb);
+      o[0] = ca * cb; o[1] = sa * cb; o[2] = ca * sb; o[3] = sa * sb;
+    }
+  } else if (which == QD_TF_DCM2QUAT) {
+    const float* R = in + 9 * i;  // scipy from_matrix: largest of (R00, R11, R22, trace) picks the branch
+    const float tr = R[0] + R[4] + R[8];
+    float w, x, y, z;
+    if (tr >= R[0] && tr >= R[4] && tr >= R[8]) {
+      x = R[7] - R[5]; y = R[2] - R[6]; z = R[3] - R[1]; w = 1.f + tr;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) {
+      x = 1.f - tr + 2.f * R[0]; y = R[3] + R[1]; z = R[6] + R[2]; w = R[7] - R[5];
+    } else if (R[4] >= R[8]) {
+      y = 1.f - tr + 2.f * R[4]; z = R[7] + R[5]; x = R[1] + R[3]; w = R[2] - R[6];
+    } else {
+      z = 1.f - tr + 2.f * R[8]; x = R[2] + R[6]; y = R[5] + R[7]; w = R[3] - R[1];
+    }
+    const float nn = 1.f / sqrtf(w * w + x * x + y * y + z * z);
+    float* o = out + 4 * i;
+    o[0] = w * nn; o[1] = x * nn; o[2] = y * nn; o[3] = z * nn;
+  }
+}
+
+}  // namespace qd
+
+// =========================================================================== C ABI
+using namespace qd;
+
+struct qd_env {
+  qd_config cfg;
+  KArgs ka;
+  ParamCfg pc;
+  uint32_t regen;
+  int D, ns;
+  bool load;
+};
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define QD_HIP(call)                                                                           \
+  do {                                                                                         \
+    hipError_t e_ = (call);                                                                    \
+    if (e_ != hipSuccess) return fail(QD_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
+  } while (0)
+#define QD_LAUNCH_CHECK() QD_HIP(hipGetLastError())
+#define QD_NEED(env) \
+  if (!(env)) return fail(QD_ERR_INVALID, "null env handle")
+
+static inline int blocks64(int n) { return (n + 63) / 64; }
+static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
+
+extern "C" {
+
+const char* qd_last_error(void) { return g_err; }
+int qd_version(void) { return QD_VERSION; }
+
+int qd_state_dim(int model) { return model == QD_MODEL_LOAD ? 33 : 29; }
+
+int qd_obs_dim(int obs_kind, int model) {
+  if (obs_kind < 0 || obs_kind >= QD_OBS_COUNT) return -1;
+  return obs_dim(obs_kind, qd_state_dim(model));
+}
+
+static inline int npad_of(int n) { return (n + PAD - 1) / PAD * PAD; }
+
+size_t qd_arena_bytes(int num_envs) {
+  if (num_envs <= 0) return 0;
+  const size_t np = (size_t)npad_of(num_envs);
+  return np * ((size_t)NUM_GROUPS * sizeof(float4) + (size_t)RAW_PLANES * sizeof(double));
+}
+
+static int needs_load_reward(int k) {
+  return (k >= QD_REW_PEND_EN && k <= QD_REW_PEND_EN4) || (k >= QD_REW_PEND_DIST && k <= QD_REW_REWARD_3);
+}
+
+int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out) {
+  if (!c || !out) return fail(QD_ERR_INVALID, "null argument");
+  if (c->num_envs <= 0) return fail(QD_ERR_INVALID, "num_envs must be positive");
+  if (c->model != QD_MODEL_LOAD && c->model != QD_MODEL_NOLOAD) return fail(QD_ERR_INVALID, "unknown model %d", c->model);
+  if (c->obs_kind < 0 || c->obs_kind >= QD_OBS_COUNT) return fail(QD_ERR_INVALID, "unknown observation variant %d", c->obs_kind);
+  if (c->obs_kind == QD_OBS_PRY_ACC_PARAMS_NOPEND)
+    return fail(QD_ERR_UNSUPPORTED, "LocalFramePRYaccParamsNoPendEnv raises NameError('acc') in the reference "
+                                    "(observation_wrappers.py:448); it has no defined output");
+  if (c->reward_kind < 0 || c->reward_kind >= QD_REW_COUNT) return fail(QD_ERR_INVALID, "unknown reward %d", c->reward_kind);
+  if (c->model == QD_MODEL_NOLOAD && needs_load_reward(c->reward_kind))
+    return fail(QD_ERR_UNSUPPORTED, "reward %d indexes params[4]/[5] of the state vector, which raises IndexError "
+                                    "on the 29-element no-load state in the reference", c->reward_kind);
+  if (c->obs_kind == QD_OBS_SIMPLE && c->model != QD_MODEL_NOLOAD)
+    return fail(QD_ERR_UNSUPPORTED, "SimpleDrone observation requires the no-load model");
+  if ((c->obs_kind == QD_OBS_SIMPLE) != (c->term_kind == QD_TERM_SIMPLE))
+    return fail(QD_ERR_INVALID, "the SimpleDrone observation and the SimpleDrone termination rule go together");
+  if (c->random_start < 0 || c->random_start > QD_START_SIMPLE) return fail(QD_ERR_INVALID, "unknown random_start %d", c->random_start);
+  if (c->frame_skip < 1) return fail(QD_ERR_INVALID, "frame_skip must be >= 1");
+  if (!(c->timestep > 0)) return fail(QD_ERR_INVALID, "timestep must be positive");
+  if (!arena) return fail(QD_ERR_ARENA, "null arena");
+  if (reinterpret_cast<uintptr_t>(arena) % 256 != 0) return fail(QD_ERR_ARENA, "arena must be 256-byte aligned");
+  if (arena_bytes < qd_arena_bytes(c->num_envs))
+    return fail(QD_ERR_ARENA, "arena has %zu bytes, need %zu", arena_bytes, qd_arena_bytes(c->num_envs));
+  qd_env* e = new (std::nothrow) qd_env;
+  if (!e) return fail(QD_ERR_INVALID, "out of host memory");
+  memset(e, 0, sizeof *e);
+  e->cfg = *c;
+  e->load = c->model == QD_MODEL_LOAD;
+  e->ns = qd_state_dim(c->model);
+  e->D = qd_obs_dim(c->obs_kind, c->model);
+  KArgs& k = e->ka;
+  k.n = c->num_envs;
+  k.npad = npad_of(c->num_envs);
+  k.g = reinterpret_cast<float4*>(arena);
+  k.raw = reinterpret_cast<double*>(k.g + (size_t)NUM_GROUPS * k.npad);
+  for (int i = 0; i < 4; i++) k.ref[i] = (float)c->reference[i];
+  k.per_env_ref = c->per_env_reference;
+  k.h = (float)c->timestep;
+  k.frame_skip = c->frame_skip; k.ctrl_map = c->ctrl_map; k.obs_kind = c->obs_kind; k.reward_kind = c->reward_kind;
+  k.term_kind = c->term_kind; k.max_distance = (float)c->max_distance; k.max_steps = c->max_steps;
+  k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
+  SampleCfg& sc = k.sc;
+  for (int i = 0; i < 4; i++) sc.start_pos[i] = (float)c->start_pos[i];
+  sc.max_pos_offset = (float)c->max_pos_offset;
+  for (int i = 0; i < 2; i++) { sc.angle_var[i] = (float)c->angle_var[i]; sc.pend_rp_var[i] = (float)c->pend_rp_var[i]; sc.pend_vel_var[i] = (float)c->pend_vel_var[i]; }
+  for (int i = 0; i < 3; i++) { sc.vel_var[i] = (float)c->vel_var[i]; sc.ang_vel_var[i] = (float)c->ang_vel_var[i]; }
+  sc.random_start = c->random_start;
+  for (int i = 0; i < 6; i++) { e->pc.center[i] = c->param_center[i]; e->pc.width[i] = c->param_width[i]; }
+  e->pc.difficulty = c->param_difficulty;
+  e->pc.random_params = c->random_params;
+  e->pc.load = e->load ? 1 : 0;
+  e->regen = 0;
+  *out = e;
+  return QD_OK;
+}
+
+int qd_destroy(qd_env* env) {
+  delete env;
+  return QD_OK;
+}
+
+int qd_init(qd_env* env, void* stream) {
+  QD_NEED(env);
+  const KArgs& k = env->ka;
+  env->regen = 0;
+  hipLaunchKernelGGL(k_init_state, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, 1);
+  QD_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_params, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, env->pc, env->regen, (const double*)nullptr, 1);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_reset_data(qd_env* env, void* stream) {
+  QD_NEED(env);
+  hipLaunchKernelGGL(k_init_state, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, 0);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_set_reference(qd_env* env, const double ref_host[4]) {
+  QD_NEED(env);
+  if (!ref_host) return fail(QD_ERR_INVALID, "null reference");
+  for (int i = 0; i < 4; i++) { env->cfg.reference[i] = ref_host[i]; env->ka.ref[i] = (float)ref_host[i]; }
+  return QD_OK;
+}
+
+int qd_set_reference_per_env(qd_env* env, const float* ref, void* stream) {
+  QD_NEED(env);
+  if (!env->ka.per_env_ref) return fail(QD_ERR_INVALID, "env was created without per_env_reference");
+  if (!ref) return fail(QD_ERR_INVALID, "null reference array");
+  hipLaunchKernelGGL(k_set_ref, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, ref);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_randomize_params(qd_env* env, void* stream) {
+  QD_NEED(env);
+  env->regen += 1;
+  hipLaunchKernelGGL(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen,
+                     (const double*)nullptr, 1);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_set_params(qd_env* env, const double* raw, void* stream) {
+  QD_NEED(env);
+  if (!raw) return fail(QD_ERR_INVALID, "null params");
+  hipLaunchKernelGGL(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen, raw, 0);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_get_params(qd_env* env, double* raw, void* stream) {
+  QD_NEED(env);
+  if (!raw) return fail(QD_ERR_INVALID, "null output");
+  hipLaunchKernelGGL(k_get_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, raw);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+#define QD_BY_MODEL(env, KERNEL, grid, block, stream, ...)                                            \
+  do {                                                                                                \
+    if ((env)->load) hipLaunchKernelGGL((KERNEL<true>), grid, block, 0, S(stream), __VA_ARGS__);      \
+    else hipLaunchKernelGGL((KERNEL<false>), grid, block, 0, S(stream), __VA_ARGS__);                 \
+    QD_LAUNCH_CHECK();                                                                                \
+  } while (0)
+
+static int launch_observe(qd_env* env, float* obs, void* stream) {
+  const KArgs& k = env->ka;
+  if (env->load) hipLaunchKernelGGL((k_observe<true, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
+  else hipLaunchKernelGGL((k_observe<false, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_reset(qd_env* env, const uint8_t* mask, float* obs, void* stream) {
+  QD_NEED(env);
+  const KArgs& k = env->ka;
+  QD_BY_MODEL(env, k_reset, dim3(blocks64(k.n)), dim3(64), stream, k, mask, -1);
+  if (obs) return launch_observe(env, obs, stream);
+  return QD_OK;
+}
+
+int qd_reset_at(qd_env* env, int index, void* stream) {
+  QD_NEED(env);
+  if (index < 0 || index >= env->ka.n) return fail(QD_ERR_INDEX, "index %d out of range [0, %d)", index, env->ka.n);
+  QD_BY_MODEL(env, k_reset, dim3(1), dim3(64), stream, env->ka, (const uint8_t*)nullptr, index);
+  return QD_OK;
+}
+
+int qd_set_state(qd_env* env, const float* qpos, const float* qvel, const float* act, void* stream) {
+  QD_NEED(env);
+  if (!qpos || !qvel) return fail(QD_ERR_INVALID, "qpos and qvel are required");
+  QD_BY_MODEL(env, k_set_state, dim3(blocks64(env->ka.n)), dim3(64), stream, env->ka, qpos, qvel, act);
+  return QD_OK;
+}
+
+int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* sensordata, int32_t* num_steps, void* stream) {
+  QD_NEED(env);
+  QD_BY_MODEL(env, k_get_state, dim3(blocks64(env->ka.n)), dim3(64), stream, env->ka, qpos, qvel, act, sensordata, num_steps);
+  return QD_OK;
+}
+
+int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward, uint8_t* truncated,
+            void* stream) {
+  QD_NEED(env);
+  const KArgs& k = env->ka;
+  if (n_action_values != (int64_t)4 * k.n) return fail(QD_ERR_SHAPE, "Action dimension mismatch");
+  if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  // one wavefront per workgroup while the batch is small (spreads 64 waves over 64 CUs);
+  // 256-thread workgroups once there are enough waves to fill the chip several times over
+  if (k.n >= 65536) {
+    const dim3 grid((k.n + 255) / 256), block(256);
+    if (env->load) hipLaunchKernelGGL((k_step<true, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    else hipLaunchKernelGGL((k_step<false, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+  } else {
+    const dim3 grid(blocks64(k.n)), block(64);
+    if (env->load) hipLaunchKernelGGL((k_step<true, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    else hipLaunchKernelGGL((k_step<false, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+  }
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
+  QD_NEED(env);
+  const KArgs& k = env->ka;
+  if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
+  if (T == 0) return QD_OK;
+  if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  const dim3 grid(blocks64(k.n)), block(64);
+  if (env->load) hipLaunchKernelGGL((k_rollout<true, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
+  else hipLaunchKernelGGL((k_rollout<false, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_observe(qd_env* env, float* obs, void* stream) {
+  QD_NEED(env);
+  if (!obs) return fail(QD_ERR_INVALID, "null output");
+  return launch_observe(env, obs, stream);
+}
+
+int qd_drone_states(qd_env* env, float* states, void* stream) {
+  QD_NEED(env);
+  if (!states) return fail(QD_ERR_INVALID, "null output");
+  QD_BY_MODEL(env, k_drone_states, dim3(blocks64(env->ka.n)), dim3(64), stream, env->ka, states);
+  return QD_OK;
+}
+
+static int eval_args(EvalArgs* a, int ns, const double ref[4], int n) {
+  if (ns != 33 && ns != 29) return fail(QD_ERR_INVALID, "state vectors have 33 or 29 entries, got %d", ns);
+  if (!ref) return fail(QD_ERR_INVALID, "null reference");
+  if (n < 0) return fail(QD_ERR_INVALID, "negative row count");
+  for (int i = 0; i < 4; i++) a->ref[i] = (float)ref[i];
+  a->n = n;
+  return QD_OK;
+}
+
+int qd_eval_obs(int obs_kind, int ns, const float* states, const double ref_host[4], float* obs, int n, void* stream) {
+  EvalArgs a{};
+  int rc = eval_args(&a, ns, ref_host, n);
+  if (rc) return rc;
+  if (obs_kind < 0 || obs_kind >= QD_OBS_SIMPLE) return fail(QD_ERR_INVALID, "unknown observation variant %d", obs_kind);
+  if (obs_kind == QD_OBS_PRY_ACC_PARAMS_NOPEND) return fail(QD_ERR_UNSUPPORTED, "variant raises NameError in the reference");
+  if (n == 0) return QD_OK;
+  if (!states || !obs) return fail(QD_ERR_INVALID, "null array argument");
+  a.kind = obs_kind;
+  a.D = obs_dim(obs_kind, ns);
+  if (ns == 33) hipLaunchKernelGGL((k_eval_obs<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
+  else hipLaunchKernelGGL((k_eval_obs<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_eval_reward(int reward_kind, int ns, const float* states, const float* actions, const int32_t* num_steps,
+                   const double ref_host[4], double max_distance, float* reward, int n, void* stream) {
+  EvalArgs a{};
+  int rc = eval_args(&a, ns, ref_host, n);
+  if (rc) return rc;
+  if (reward_kind < 0 || reward_kind >= QD_REW_COUNT) return fail(QD_ERR_INVALID, "unknown reward %d", reward_kind);
+  if (ns == 29 && needs_load_reward(reward_kind)) return fail(QD_ERR_UNSUPPORTED, "reward needs the 33-element state");
+  if (n == 0) return QD_OK;
+  if (!states || !actions || !reward) return fail(QD_ERR_INVALID, "null array argument");
+  a.kind = reward_kind;
+  a.max_distance = (float)max_distance;
+  if (ns == 33) hipLaunchKernelGGL((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
+  else hipLaunchKernelGGL((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_eval_truncated(int ns, const float* states, const int32_t* num_steps, const double ref_host[4], double max_distance,
+                      int max_steps, uint8_t* truncated, int n, void* stream) {
+  EvalArgs a{};
+  int rc = eval_args(&a, ns, ref_host, n);
+  if (rc) return rc;
+  if (n == 0) return QD_OK;
+  if (!states || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  a.max_distance = (float)max_distance;
+  a.max_steps = max_steps;
+  if (ns == 33) hipLaunchKernelGGL((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
+  else hipLaunchKernelGGL((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_transform(int which, const float* in, float* out, int n, void* stream) {
+  if (which < QD_TF_QUAT2RPY || which > QD_TF_PENDRP2QUAT) return fail(QD_ERR_INVALID, "unknown transform %d", which);
+  if (n < 0) return fail(QD_ERR_INVALID, "negative row count");
+  if (n == 0) return QD_OK;
+  if (!in || !out) return fail(QD_ERR_INVALID, "null array argument");
+  hipLaunchKernelGGL(k_transform, dim3(blocks64(n)), dim3(64), 0, S(stream), which, in, out, n);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+// qd_model.h -- closed-form replacement of the reference's model generator.
+//
+// The reference builds an MJCF document per drone (environments/env_gen.py:7-73),
+// serialises it with 5 significant digits (env_gen.py:129) and lets MuJoCo's
+// compiler derive masses, centres of mass and principal inertias from the geoms.
+// Here the same quantities are derived directly from the six raw parameters
+// (mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass;
+// BaseDroneEnv.py:208-214), in float64, one drone per lane, and stored as the 13
+// per-env float32 constants the step kernel needs.  No XML, no compile step.
+//
+// Symmetry facts used (verified against the general oracle in the tests):
+//   * the four arms/motors sit at +-45 deg, so the core's inertia tensor about its
+//     COM is diagonal in body axes to < 1e-12 and its COM is on the z axis; MuJoCo's
+//     principal frame is then a signed axis permutation and the inertia-box fluid
+//     forces, which are odd per axis, are identical when evaluated in body axes;
+//   * the link sphere and the rod/load stack are axially symmetric about the tether.
+#pragma once
+#include "qd_math.h"
+
+namespace qd {
+
+// constants of the reference model that do not depend on the per-drone parameters
+// (already exact to 5 significant digits)
+struct Const {
+  static constexpr double gravity = 9.81;       // MuJoCo default, z down
+  static constexpr double density = 1.2;        // env_gen.py:83
+  static constexpr double viscosity = 0.00002;  // env_gen.py:84
+  static constexpr double damping = 0.15;       // env_gen.py:23 (hinges only; the freejoint takes no defaults)
+  static constexpr double hb = 0.05;            // env_gen.py:38 half body size
+  static constexpr double anchor_z = -0.025;    // env_gen.py:66 link body position
+  static constexpr double sense_z = -0.0125;    // env_gen.py:48 accelerometer site
+  static constexpr double m1 = 0.01;            // env_gen.py:68 link sphere mass
+  static constexpr double r1 = 0.02;            //               and radius
+  static constexpr double I1 = 0.4 * 0.01 * 0.02 * 0.02;  // solid sphere
+};
+
+// per-env derived constants (float32 on the device; 13 used, padded to 4 float4)
+template <class T>
+struct Model {
+  T m0, c0z, I0x, I0y;        // group M0
+  T I0z, rot, gearF, gearT;   // group M1
+  T inv_tau, m2, lc, I2t;     // group M2
+  T I2a, pad0, pad1, pad2;    // group M3
+};
+
+// round to 5 significant digits the way "%.5g" + strtod does (env_gen.py:129)
+QD_HD double round5(double x) {
+  if (x == 0.0) return 0.0;
+  const double ax = fabs(x);
+  int e = (int)floor(log10(ax));
+  // 10^k is exact in binary64 for 0 <= k <= 22
+  const double p10[] = {1e0, 1e1, 1e2, 1e3, 1e4, 1e5, 1e6, 1e7, 1e8, 1e9, 1e10, 1e11, 1e12, 1e13, 1e14};
+  int k = 4 - e;
+  double r;
+  if (k >= 0) {
+    if (k > 14) k = 14;
+    r = rint(ax * p10[k]) / p10[k];
+  } else {
+    k = -k;
+    if (k > 14) k = 14;
+    r = rint(ax / p10[k]) * p10[k];
+  }
+  return x < 0 ? -r : r;
+}
+
+// raw = (mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass)
+// returns the derived constants in double; `load` = pendulum present
+QD_HD Model<double> derive_model(const double raw[6], bool* load_out) {
+  Model<double> M;
+  const double mass = raw[0], L = raw[1], F = raw[2], tau = raw[3], pl = raw[4], wm = raw[5];
+  const double hb = Const::hb;
+  // geom masses (env_gen.py:41-43)
+  const double mb = round5(0.56 * mass), ma = round5(0.07 * mass), mm = round5(0.04 * mass);
+  // core box half sizes (hb, hb, hb/3)
+  const double bx = round5(hb), bz = round5(hb / 3);
+  // arm box half sizes (L/2, L/20, L/20), centre radius A, rotated by +-45 deg
+  const double al = round5(L / 2), aw = round5(L / 20);
+  const double cs = 0.70710678118654752440;  // |cos|=|sin| of (i*pi/2 - pi/4)
+  const double pa = round5((1.4142135623730951 * hb + 0.5 * L) * cs);  // |x|=|y| of arm centres
+  const double pm = round5((1.4142135623730951 * hb + L) * cs);        // |x|=|y| of motor sites
+  const double mz = round5(0.015), mr = round5(0.01), mh = round5(0.01);
+  // total mass and COM (on the z axis)
+  const double m0 = mb + 4 * ma + 4 * mm;
+  const double cz = 4 * mm * mz / m0;
+  // inertia about the COM, body axes.  Arm box inertia in its own frame:
+  const double Ial = ma / 3 * (aw * aw + aw * aw);   // about the long axis
+  const double Iat = ma / 3 * (al * al + aw * aw);   // about the short axes
+  // rotated by theta = +-45 deg about z: Ixx = Iyy = (Ial + Iat)/2 up to the 1e-10 asymmetry the
+  // 5-digit Euler angles introduce, which the reference oracle carries and the tests bound
+  const double th0 = round5(0.78539816339744830962);   // |theta| of arms 0,1 as printed: 0.7854
+  const double th2 = round5(2.35619449019234492885);   // 2.3562
+  const double th3 = round5(3.92699081698724154808);   // 3.927
+  const double c0 = cos(th0), s0 = sin(th0), c2 = cos(th2), s2 = sin(th2), c3 = cos(th3), s3 = sin(th3);
+  const double armxx = 2 * (c0 * c0 * Ial + s0 * s0 * Iat) + (c2 * c2 * Ial + s2 * s2 * Iat) + (c3 * c3 * Ial + s3 * s3 * Iat);
+  const double armyy = 2 * (s0 * s0 * Ial + c0 * c0 * Iat) + (s2 * s2 * Ial + c2 * c2 * Iat) + (s3 * s3 * Ial + c3 * c3 * Iat);
+  const double armzz = 4 * Iat;
+  const double Imt = mm * (3 * mr * mr + 4 * mh * mh) / 12, Imz = mm * mr * mr / 2;  // motor cylinder
+  const double dzb = 0 - cz, dzm = mz - cz;  // geom centre offsets from the COM
+  M.I0x = mb / 3 * (bx * bx + bz * bz) + mb * dzb * dzb + armxx + 4 * ma * (pa * pa + dzb * dzb) +
+          4 * Imt + 4 * mm * (pm * pm + dzm * dzm);
+  M.I0y = mb / 3 * (bx * bx + bz * bz) + mb * dzb * dzb + armyy + 4 * ma * (pa * pa + dzb * dzb) +
+          4 * Imt + 4 * mm * (pm * pm + dzm * dzm);
+  M.I0z = mb / 3 * (bx * bx + bx * bx) + armzz + 4 * ma * (2 * pa * pa) + 4 * Imz + 4 * mm * (2 * pm * pm);
+  M.m0 = m0;
+  M.c0z = cz;
+  M.rot = pm;
+  M.gearF = round5(F);
+  M.gearT = round5(F / 100);
+  const double t = round5(tau);
+  M.inv_tau = 1.0 / (t > 1e-15 ? t : 1e-15);
+  const bool load = (pl > 0 && wm > 0);  // env_gen.py:33-35
+  M.m2 = M.lc = M.I2t = M.I2a = 0;
+  if (load) {
+    const double mp = round5(0.2 * pl), mw = round5(wm);
+    const double rr = round5(0.005), rh = round5(pl / 2), rz = round5(-pl / 2);
+    const double bs = round5(0.1 * cbrt(wm)), wz = round5(-pl);
+    const double m2 = mp + mw, c2z = (mp * rz + mw * wz) / m2;
+    const double d_r = rz - c2z, d_w = wz - c2z;
+    M.m2 = m2;
+    M.lc = -c2z;
+    M.I2t = mp * (3 * rr * rr + 4 * rh * rh) / 12 + mp * d_r * d_r + mw / 3 * (2 * bs * bs) + mw * d_w * d_w;
+    M.I2a = mp * rr * rr / 2 + mw / 3 * (2 * bs * bs);
+  }
+  M.pad0 = M.pad1 = M.pad2 = 0;
+  *load_out = load;
+  return M;
+}
+
+}  // namespace qd

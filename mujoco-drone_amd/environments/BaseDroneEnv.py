@@ -1,0 +1,408 @@
+"""GPU-backed `BaseDroneEnv`: N drones (+ hanging loads) stepped by one HIP kernel launch.
+
+Mirrors the surface of the reference class (environments/BaseDroneEnv.py:53-387): the
+same config keys and defaults (`base_config`, :19-50; key reads :60-106), the RLlib
+`VectorEnv` methods `vector_reset` / `reset_at` / `vector_step` (:259-351) with the same
+return structure, and the attributes scripts touch (`reference`, `states`,
+`drone_params`, `num_envs`, `observation_space`, `action_space`).  On top of that it
+offers zero-copy tensor methods (`vector_step_tensor`, `vector_reset_tensor`,
+`rollout_tensor`) that never leave the GPU.
+
+Differences a user can observe (all listed in DESIGN.md):
+  * random numbers come from per-env Philox streams on the device, not from one
+    sequential numpy PCG64 stream, so sampled states/params differ draw-for-draw while the
+    draw -> value transforms are identical;
+  * arithmetic is float32 on the device (the reference is float64);
+  * floor contact is not modelled (the training configs fly at z = 15 m and truncate at
+    4 m from the reference point).
+"""
+import types
+
+import numpy as np
+
+from .. import _lib as L
+from . import rewards as _rewards
+from ._device import DeviceEnv
+from .rewards import default_reward_fcn
+
+try:  # RLlib / gymnasium are optional: only needed when the env is handed to RLlib
+    from ray.rllib.env.vector_env import VectorEnv as _VectorEnvBase
+except Exception:  # pragma: no cover - not installed in the build image
+    class _VectorEnvBase:
+        def __init__(self, observation_space, action_space, num_envs):
+            self.observation_space, self.action_space, self.num_envs = observation_space, action_space, num_envs
+
+try:
+    from gymnasium.spaces import Box
+except Exception:  # pragma: no cover
+    class Box:
+        """minimal stand-in for gymnasium.spaces.Box"""
+
+        def __init__(self, low, high, shape=None, dtype=np.float64, seed=None):
+            self.shape = tuple(shape)
+            self.dtype = np.dtype(dtype)
+            self.low = np.full(self.shape, low, dtype=self.dtype)
+            self.high = np.full(self.shape, high, dtype=self.dtype)
+            self._rng = seed if isinstance(seed, np.random.Generator) else np.random.default_rng(seed)
+
+        def sample(self):
+            lo = np.where(np.isfinite(self.low), self.low, -1.0)
+            hi = np.where(np.isfinite(self.high), self.high, 1.0)
+            return self._rng.uniform(lo, hi).astype(self.dtype)
+
+        def contains(self, x):
+            x = np.asarray(x)
+            return x.shape == self.shape and bool(np.all(x >= self.low) and np.all(x <= self.high))
+
+
+def default_termination_fcn(env, state, action, num_steps):
+    """truncate if too far from the reference or if the episode is too long (BaseDroneEnv.py:12-16);
+    evaluated by the same device code the step kernel uses"""
+    from ._device import eval_truncated
+    out = eval_truncated(np.asarray(state), [int(num_steps)], env.reference, env.max_distance, env.max_steps)
+    return bool(out[0].item())
+
+
+# same keys and values as the reference's base_config (BaseDroneEnv.py:19-50)
+base_config = {'seed': 42,
+               'frequency': 100,
+               'skip_steps': 1,
+               'reference': [0, 0, 15, 0],
+               'start_pos': [0, 0, 15, 0],
+               'max_distance': 4,
+               'random_start_pos': True,
+               'random_params': True,
+               'pendulum': True,
+               'state_difficulty': 0.4,
+               'param_difficulty': 0.1,
+               'max_random_offset': 2,
+               'rp_variance': [0.8, 0.8],
+               'vel_variance': [1, 1, 1],
+               'ang_vel_variance': [1, 1, 1],
+               'mass_interval': [1, 0.1],
+               'arm_len_interval': [0.17, 0.02],
+               'motor_force_interval': [7, 1],
+               'motor_tau_interval': [0.01, 0.0025],
+               'pendulum_length_interval': [1.2, 0.2],
+               'weight_mass_interval': [0.3, 0.05],
+               'pendulum_rp_variance': [0.5, 0.5],
+               'pendulum_ang_vel_variance': [0.5, 0.5],
+               'reward_fcn': default_reward_fcn,
+               'terminated_fcn': default_termination_fcn,
+               'max_steps': 512,
+               'regen_env_at_steps': None,
+               'train_vis': 0,
+               'window_title': 'mujoco',
+               'controlled': False,
+               'mocaps': 1
+               }
+
+PARAM_NAMES = ('mass', 'arm_len', 'motor_force', 'motor_tau', 'pendulum_len', 'weight_mass')
+
+
+class BaseDroneEnv(_VectorEnvBase):
+    OBS_KIND = 0  # BaseDroneEnv._get_obs returns the raw state vectors (BaseDroneEnv.py:353-355)
+
+    def __init__(self, config, **kwargs):
+        # --- the key reads of BaseDroneEnv.py:60-106, same defaults -------------------
+        self.controlled = config.get('controlled', False)
+        if self.controlled:
+            raise NotImplementedError("joystick reference control (BaseDroneEnv.py:151-172) is a human-in-the-loop UI "
+                                      "and is not part of the GPU env")
+        self.render_mode = None  # rendering is out of scope; render() is a no-op
+        self.window_title = config.get('window_title', 'mujoco')
+        self.mocaps = config.get('mocaps', 1)
+        self.skip_steps = config.get('skip_steps', 1)
+        self.frequency = config.get('frequency', 200)
+        self._reference = config.get('reference', [0, 0, 0, 0])
+        self.num_drones = config.get('num_drones', 1)
+        self.pendulum = config.get('pendulum', True)
+        self.mass_interval = np.array(config.get('mass_interval', [1.35, 0.15]))
+        self.arm_len_interval = np.array(config.get('arm_len_interval', [0.17, 0.02]))
+        self.motor_force_interval = np.array(config.get('motor_force_interval', [7.5, 1.5]))
+        self.motor_tau_interval = np.array(config.get('motor_tau_interval', [0.003, 0.002]))
+        self.pendulum_length_interval = np.array(config.get('pendulum_length_interval', [1.2, 0.3]))
+        self.weight_mass_interval = np.array(config.get('weight_mass_interval', [0.2, 0.1]))
+        self.state_difficulty = config.get('state_difficulty', 0.1)
+        self.param_difficulty = config.get('param_difficulty', 0.1)
+        self.random_start_pos = config.get('random_start_pos', False)
+        self.random_params = config.get('random_params', False)
+        self.regen_env_at_steps = config.get('regen_env_at_steps', None)
+        self.start_pos = config.get('start_pos', self._reference)
+        self.max_distance = config.get('max_distance', 1)
+        self.reward_fcn = config.get('reward_fcn', default_reward_fcn)
+        self.terminated_fcn = config.get('terminated_fcn', default_termination_fcn)
+        self.max_steps = config.get('max_steps', 512)
+        self.max_pos_offset = self.state_difficulty * config.get('max_random_offset', 0)
+        # QUIRK C-3: 'rp_variance' of base_config is never read; the key is 'angle_variance'
+        self.angle_variance = self.state_difficulty * np.array(config.get('angle_variance', [0, 0]))
+        self.ang_vel_variance = self.state_difficulty * np.array(config.get('ang_vel_variance', [0, 0, 0]))
+        self.vel_variance = self.state_difficulty * np.array(config.get('vel_variance', [0, 0, 0]))
+        self.pendulum_rp_variance = self.state_difficulty * np.array(config.get('pendulum_rp_variance', [0, 0]))
+        self.pendulum_ang_vel_variance = self.state_difficulty * np.array(config.get('pendulum_ang_vel_variance', [0, 0]))
+
+        self.total_steps = 0
+        # QUIRK C-4: the worker index is looked up as a dict KEY (BaseDroneEnv.py:113), which RLlib's
+        # EnvContext does not provide, so every worker ends up with seed + 0
+        self.seed_value = int(config.get('worker_index', -1) + 1 + config.get('seed', 1))
+        self.np_random = np.random.default_rng(self.seed_value)
+
+        # --- extensions (keys the reference does not have) ------------------------------
+        self.device = config.get('device', 'cuda:0')
+        self.auto_reset = bool(config.get('auto_reset', False))
+        self.per_env_reference = bool(config.get('per_env_reference', False))
+        self.fresh_reset_obs = bool(config.get('fresh_reset_obs', False))  # False = reference behaviour (C-1)
+
+        if getattr(self.terminated_fcn, '__name__', None) != 'default_termination_fcn':
+            raise TypeError("terminated_fcn must be default_termination_fcn: the device step implements the "
+                            "reference's truncation rule (BaseDroneEnv.py:12-16) only")
+
+        self.num_params = 6
+        self.num_states = 27 if self.pendulum else 23
+        cfg = self._make_cfg()
+        self._dev = DeviceEnv(cfg, self.device)
+        D = self._dev.D
+        self.observation_space = Box(low=-np.inf, high=np.inf, shape=(D,), dtype=np.float64)
+        self.action_space = Box(low=0, high=1, shape=(4,), dtype=np.float64, seed=self.np_random)
+        self.frame_skip = self.skip_steps
+        self.metadata = {"render_modes": ["human", "rgb_array", "depth_array"],
+                         "render_fps": self.frequency // self.skip_steps}
+        self.model = types.SimpleNamespace(nq=self._dev.nq * self.num_drones, nv=self._dev.nv * self.num_drones,
+                                           nu=4 * self.num_drones, na=4 * self.num_drones,
+                                           opt=types.SimpleNamespace(timestep=1.0 / self.frequency))
+        _VectorEnvBase.__init__(self, self.observation_space, self.action_space, self.num_drones)
+        self.num_envs = self.num_drones
+        self._host_cache = {}
+        self._obs_host = None
+        self.num_steps = np.zeros((self.num_drones,), dtype=np.int64)
+        qpos, qvel = self._flat_state()[:2]
+        self.init_qpos, self.init_qvel = qpos.copy(), qvel.copy()
+
+    # -------------------------------------------------------------------- configuration
+    def _make_cfg(self):
+        c = L.QdConfig()
+        c.num_envs = int(self.num_drones)
+        c.model = L.MODEL_LOAD if self.pendulum else L.MODEL_NOLOAD
+        c.obs_kind = int(self.OBS_KIND)
+        if c.obs_kind == L.OBS_KINDS.index("LocalFramePRYaccParamsNoPendEnv"):
+            raise NameError("name 'acc' is not defined")  # what the reference raises on first use (:448)
+        c.reward_kind = _rewards.resolve(self.reward_fcn)
+        if not self.pendulum and c.reward_kind in (6, 7, 8, 9, 12, 13, 14, 15, 16):
+            raise IndexError("index 4 is out of bounds for axis 0 with size 2")  # params[4] on the 29-vector
+        c.frame_skip = int(self.skip_steps)
+        c.max_steps = int(self.max_steps)
+        c.ctrl_map, c.term_kind = L.CTRL_AFFINE, L.TERM_DEFAULT
+        c.random_start = L.START_RANDOM if self.random_start_pos else L.START_FIXED
+        c.random_params = int(bool(self.random_params))
+        c.auto_reset = int(self.auto_reset)
+        c.per_env_reference = int(self.per_env_reference)
+        c.timestep = 1.0 / self.frequency
+        c.max_distance = float(self.max_distance)
+        c.reference[:] = [float(x) for x in self._reference]
+        c.start_pos[:] = [float(x) for x in self.start_pos]
+        c.max_pos_offset = float(self.max_pos_offset)
+        c.angle_var[:] = [float(x) for x in self.angle_variance]
+        c.vel_var[:] = [float(x) for x in self.vel_variance]
+        c.ang_vel_var[:] = [float(x) for x in self.ang_vel_variance]
+        c.pend_rp_var[:] = [float(x) for x in self.pendulum_rp_variance]
+        c.pend_vel_var[:] = [float(x) for x in self.pendulum_ang_vel_variance]
+        ivs = (self.mass_interval, self.arm_len_interval, self.motor_force_interval, self.motor_tau_interval,
+               self.pendulum_length_interval, self.weight_mass_interval)
+        c.param_center[:] = [float(iv[0]) for iv in ivs]
+        c.param_width[:] = [float(iv[1]) for iv in ivs]
+        c.param_difficulty = float(self.param_difficulty)
+        c.seed = self.seed_value & 0xFFFFFFFFFFFFFFFF
+        return c
+
+    # ----------------------------------------------------------------------- attributes
+    @property
+    def reference(self):
+        return self._reference
+
+    @reference.setter
+    def reference(self, value):
+        self._reference = value
+        self._dev.set_reference(value)
+
+    def _push_reference(self):
+        self._dev.set_reference(self._reference)  # also catches in-place edits of the list/array
+
+    @property
+    def dt(self):
+        return self.model.opt.timestep * self.frame_skip
+
+    def _invalidate(self):
+        self._host_cache = {}
+
+    def _flat_state(self):
+        """(qpos, qvel, act, sensordata) as flat float64 arrays in MuJoCo's order"""
+        if 'flat' not in self._host_cache:
+            qpos, qvel, act, sens, steps = self._dev.get_state()
+            self._host_cache['flat'] = tuple(x.cpu().numpy().astype(np.float64).ravel() for x in (qpos, qvel, act, sens))
+            self._host_cache['steps'] = steps.cpu().numpy().astype(np.int64)
+        return self._host_cache['flat']
+
+    @property
+    def data(self):
+        """read-only view with MjData's field names (qpos, qvel, act, sensordata)"""
+        qpos, qvel, act, sens = self._flat_state()
+        return types.SimpleNamespace(qpos=qpos, qvel=qvel, act=act, sensordata=sens, ctrl=None)
+
+    @property
+    def states(self):
+        """list of per-drone state vectors (BaseDroneEnv.py:148,273,325).  QUIRK C-1: like the reference,
+        the list is refreshed by vector_step / reset_model, NOT by reset_at."""
+        if 'states' not in self._host_cache:
+            self._host_cache['states'] = list(self._dev.drone_states().cpu().numpy().astype(np.float64))
+        return self._host_cache['states']
+
+    @property
+    def drone_params(self):
+        """list of per-drone parameter dicts (BaseDroneEnv.py:207-216), float64"""
+        if 'params' not in self._host_cache:
+            raw = self._dev.get_params().cpu().numpy()
+            self._host_cache['params'] = [dict(zip(PARAM_NAMES, (float(v) for v in row))) for row in raw]
+        return self._host_cache['params']
+
+    def model_constants(self):
+        return {k: v.cpu().numpy() for k, v in self._dev.model_constants().items()}
+
+    # ------------------------------------------------------------- reference's methods
+    def move_mocap_to(self, pose, idx=0):
+        """visual marker only in the reference (BaseDroneEnv.py:174-178); accepted and ignored"""
+        assert idx < self.mocaps
+
+    def control_reference(self):
+        raise NotImplementedError("joystick control is out of scope")
+
+    def render(self, mode=None):
+        return None
+
+    def close(self):
+        return None
+
+    def get_drone_states(self):
+        self._host_cache.pop('states', None)
+        return self.states
+
+    def _get_obs(self):
+        """list of N observation vectors (float64) for the current `states` snapshot"""
+        if self._obs_host is None:
+            self._obs_host = self._dev.observe().cpu().numpy().astype(np.float64)
+        return list(self._obs_host)
+
+    def set_state(self, qpos, qvel):
+        """mujoco_vecenv.py:396-402: flat qpos (nq) / qvel (nv), then mj_forward; activations persist"""
+        qpos, qvel = np.asarray(qpos, dtype=np.float64), np.asarray(qvel, dtype=np.float64)
+        assert qpos.shape == (self.model.nq,) and qvel.shape == (self.model.nv,)
+        self._dev.set_state(qpos.reshape(self.num_drones, -1), qvel.reshape(self.num_drones, -1))
+        self._host_cache.pop('flat', None)
+
+    def reset_model(self, regen=False):
+        """BaseDroneEnv.py:296-326"""
+        if regen:
+            self._dev.randomize_params()
+        self._dev.reset(None, want_obs=True)
+        self.num_steps = np.zeros((self.num_drones,), dtype=np.int64)
+        self._invalidate()
+        self._obs_host = self._dev.obs.cpu().numpy().astype(np.float64)
+        return list(self._obs_host)
+
+    def reset(self, *, seed=None, options=None):
+        """gym path (mujoco_vecenv.py:309-322): mj_resetData, then reset_model"""
+        self._dev.reset_data()
+        ob = self.reset_model()
+        return ob, {}
+
+    def vector_reset(self, seeds=None, options=None):
+        """BaseDroneEnv.py:328-332"""
+        obs = self.reset_model()
+        infos = [{}] * self.num_drones
+        return obs, infos
+
+    def reset_at(self, index, seed=None, options=None):
+        """BaseDroneEnv.py:334-351.  QUIRK C-1: the reference answers with the observation computed from the
+        states of BEFORE the reset; pass config['fresh_reset_obs']=True for the post-reset observation."""
+        if index is None:
+            index = 0
+        assert index < self.num_drones
+        self._dev.reset_at(index)
+        self.num_steps[index] = 0
+        self._host_cache.pop('flat', None)
+        if self.fresh_reset_obs:
+            self._host_cache.pop('states', None)
+            self._obs_host = None
+        ob = self._get_obs()[index]
+        return ob, {}
+
+    def vector_step(self, actions):
+        """BaseDroneEnv.py:259-294: list/array of N 4-vectors in [0,1] ->
+        (obs list, rewards list, dones list, truncated list | ndarray, infos list)"""
+        self._push_reference()
+        acts = np.asarray(actions, dtype=np.float32)
+        if acts.size != 4 * self.num_drones:
+            raise ValueError("Action dimension mismatch")
+        obs, rew, trunc = self._dev.step(acts)
+        self.num_steps = self.num_steps + 1
+        self.total_steps += 1
+        self._invalidate()
+        rewards = rew.cpu().numpy().astype(np.float64).tolist()
+        truncated = trunc.cpu().numpy().astype(bool).tolist()
+        dones = [False] * self.num_drones
+        infos = [{} for _ in range(self.num_drones)]
+        if self.auto_reset:
+            self.num_steps = np.where(np.asarray(truncated), 0, self.num_steps)
+        if self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps:
+            self.total_steps = 0
+            self.reset_model(regen=True)
+            truncated = np.ones(self.num_drones, dtype=bool)  # QUIRK C-5: becomes an ndarray
+            return list(self._obs_host), rewards, dones, truncated, infos
+        self._obs_host = obs.cpu().numpy().astype(np.float64)
+        return list(self._obs_host), rewards, dones, truncated, infos
+
+    # ----------------------------------------------------------------- tensor fast path
+    def vector_reset_tensor(self):
+        """reset every env; returns the device observation tensor [N, D] (float32)"""
+        obs = self._dev.reset(None, want_obs=True)
+        self.num_steps[:] = 0
+        self._invalidate()
+        self._obs_host = None
+        return obs
+
+    def vector_step_tensor(self, actions, out=None):
+        """actions: float32 CUDA tensor [N,4].  Returns device tensors (obs [N,D] f32, reward [N] f32,
+        truncated [N] u8); they alias internal buffers (or `out=(obs, reward, truncated)`) and stay valid
+        until the next step.  The regen rule of vector_step is applied."""
+        self._push_reference()
+        o, r, t = out if out is not None else (None, None, None)
+        obs, rew, trunc = self._dev.step(actions, o, r, t)
+        self.total_steps += 1
+        self._invalidate()
+        self._obs_host = None
+        if self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps:
+            self.total_steps = 0
+            self._dev.randomize_params()
+            self._dev.reset(None, want_obs=False)
+            self._dev.observe(obs)
+            trunc.fill_(1)
+        return obs, rew, trunc
+
+    def rollout_tensor(self, actions):
+        """T steps in one kernel launch: actions [T,N,4] -> (obs [T,N,D], reward [T,N], truncated [T,N])"""
+        self._push_reference()
+        out = self._dev.rollout(actions)
+        self.total_steps += int(actions.shape[0])
+        self._invalidate()
+        self._obs_host = None
+        return out
+
+    def reset_mask_tensor(self, mask):
+        """re-sample the envs with mask != 0 (device tensor); returns fresh observations [N,D]"""
+        obs = self._dev.reset(mask, want_obs=True)
+        self._invalidate()
+        self._obs_host = None
+        return obs
+
+    def set_reference_tensor(self, ref):
+        """per-env references [N,4] (needs config['per_env_reference']=True)"""
+        self._dev.set_reference_per_env(ref)

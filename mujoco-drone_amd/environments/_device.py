@@ -1,0 +1,222 @@
+"""Device-side env batch: owns the torch tensors (arena + output buffers) and the
+qd_env handle, and exposes every C-ABI call as a method taking/returning torch
+tensors.  PyTorch is used for device memory and streams only."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class DeviceEnv:
+    def __init__(self, cfg: L.QdConfig, device="cuda:0"):
+        self.lib = L.lib()  # raises if libqd.so is missing: no CPU path
+        if not torch.cuda.is_available():
+            raise RuntimeError("mujoco_drone_amd needs a ROCm GPU (torch.cuda.is_available() is False); "
+                               "there is no CPU fallback")
+        self.device = torch.device(device)
+        self.cfg = cfg
+        self.n = int(cfg.num_envs)
+        self.load = cfg.model == L.MODEL_LOAD
+        self.nq, self.nv = (9, 8) if self.load else (7, 6)
+        self.ns = self.lib.qd_state_dim(cfg.model)
+        self.D = self.lib.qd_obs_dim(cfg.obs_kind, cfg.model)
+        nbytes = self.lib.qd_arena_bytes(self.n)
+        with torch.cuda.device(self.device):
+            # torch's caching allocator hands out 512-byte aligned blocks
+            self.arena = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+            self.obs = torch.zeros((self.n, max(self.D, 1)), dtype=torch.float32, device=self.device)
+            self.reward = torch.zeros(self.n, dtype=torch.float32, device=self.device)
+            self.truncated = torch.zeros(self.n, dtype=torch.uint8, device=self.device)
+        handle = C.c_void_p()
+        L.check(self.lib.qd_create(C.byref(cfg), _ptr(self.arena), nbytes, C.byref(handle)))
+        self.handle = handle
+        L.check(self.lib.qd_init(self.handle, self._stream()))
+
+    def __del__(self):
+        try:
+            if getattr(self, "handle", None):
+                self.lib.qd_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, x, shape):
+        t = torch.as_tensor(x)
+        if t.device != self.device or t.dtype != torch.float32 or not t.is_contiguous():
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            if t.numel() != int(np.prod(shape)):
+                raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+            t = t.reshape(shape)
+        return t
+
+    # ------------------------------------------------------------------ calls
+    def set_reference(self, ref):
+        L.check(self.lib.qd_set_reference(self.handle, L.double4(ref)))
+
+    def set_reference_per_env(self, ref):
+        ref = self._f32(ref, (self.n, 4))
+        L.check(self.lib.qd_set_reference_per_env(self.handle, _ptr(ref), self._stream()))
+
+    def randomize_params(self):
+        L.check(self.lib.qd_randomize_params(self.handle, self._stream()))
+
+    def set_params(self, raw):
+        raw = torch.as_tensor(np.asarray(raw, dtype=np.float64)).to(self.device).contiguous().reshape(self.n, 6)
+        L.check(self.lib.qd_set_params(self.handle, _ptr(raw), self._stream()))
+
+    def get_params(self):
+        out = torch.empty((self.n, 6), dtype=torch.float64, device=self.device)
+        L.check(self.lib.qd_get_params(self.handle, _ptr(out), self._stream()))
+        return out
+
+    def reset_data(self):
+        L.check(self.lib.qd_reset_data(self.handle, self._stream()))
+
+    def reset(self, mask=None, want_obs=True):
+        if mask is not None:
+            mask = torch.as_tensor(mask).to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.n:
+                raise ValueError("mask must have one entry per env")
+        L.check(self.lib.qd_reset(self.handle, _ptr(mask), _ptr(self.obs) if want_obs else None, self._stream()))
+        return self.obs if want_obs else None
+
+    def reset_at(self, index):
+        L.check(self.lib.qd_reset_at(self.handle, int(index), self._stream()))
+
+    def set_state(self, qpos, qvel, act=None):
+        qpos = self._f32(qpos, (self.n, self.nq))
+        qvel = self._f32(qvel, (self.n, self.nv))
+        act = self._f32(act, (self.n, 4)) if act is not None else None
+        L.check(self.lib.qd_set_state(self.handle, _ptr(qpos), _ptr(qvel), _ptr(act), self._stream()))
+
+    def get_state(self):
+        kw = dict(dtype=torch.float32, device=self.device)
+        qpos, qvel = torch.empty((self.n, self.nq), **kw), torch.empty((self.n, self.nv), **kw)
+        act, sens = torch.empty((self.n, 4), **kw), torch.empty((self.n, 3), **kw)
+        steps = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        L.check(self.lib.qd_get_state(self.handle, _ptr(qpos), _ptr(qvel), _ptr(act), _ptr(sens), _ptr(steps),
+                                      self._stream()))
+        return qpos, qvel, act, sens, steps
+
+    def step(self, actions, obs=None, reward=None, truncated=None):
+        """actions: float32 device tensor with 4*N values (anything else raises ValueError like the reference)."""
+        if not (isinstance(actions, torch.Tensor) and actions.device == self.device and
+                actions.dtype == torch.float32 and actions.is_contiguous()):
+            actions = torch.as_tensor(np.asarray(actions, dtype=np.float32) if not isinstance(actions, torch.Tensor)
+                                      else actions).to(device=self.device, dtype=torch.float32).contiguous()
+        obs = self.obs if obs is None else obs
+        reward = self.reward if reward is None else reward
+        truncated = self.truncated if truncated is None else truncated
+        L.check(self.lib.qd_step(self.handle, _ptr(actions), actions.numel(), _ptr(obs), _ptr(reward), _ptr(truncated),
+                                 self._stream()))
+        return obs, reward, truncated
+
+    def rollout(self, actions, obs=None, reward=None, truncated=None):
+        """actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N] in one launch."""
+        actions = self._f32(actions, tuple(actions.shape))
+        T = int(actions.shape[0])
+        if tuple(actions.shape[1:]) != (self.n, 4):
+            raise ValueError("Action dimension mismatch")
+        kw = dict(device=self.device)
+        obs = torch.empty((T, self.n, self.D), dtype=torch.float32, **kw) if obs is None else obs
+        reward = torch.empty((T, self.n), dtype=torch.float32, **kw) if reward is None else reward
+        truncated = torch.empty((T, self.n), dtype=torch.uint8, **kw) if truncated is None else truncated
+        L.check(self.lib.qd_rollout(self.handle, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(truncated),
+                                    self._stream()))
+        return obs, reward, truncated
+
+    def observe(self, out=None):
+        out = self.obs if out is None else out
+        L.check(self.lib.qd_observe(self.handle, _ptr(out), self._stream()))
+        return out
+
+    def drone_states(self):
+        out = torch.empty((self.n, self.ns), dtype=torch.float32, device=self.device)
+        L.check(self.lib.qd_drone_states(self.handle, _ptr(out), self._stream()))
+        return out
+
+    def model_constants(self):
+        """per-env derived model constants (qd_model.h), read straight from the arena planes"""
+        npad = (self.n + 255) // 256 * 256
+        g = self.arena[:14 * npad * 16].view(torch.float32).view(14, npad, 4)[:, :self.n]
+        names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "m2", "lc", "I2t", "I2a"]
+        flat = torch.cat([g[7], g[8], g[9], g[10]], dim=1)
+        return {k: flat[:, i].clone() for i, k in enumerate(names)}
+
+
+# ---------------------------------------------------------------- stateless helpers
+def _dev(device=None):
+    if not torch.cuda.is_available():
+        raise RuntimeError("mujoco_drone_amd needs a ROCm GPU; there is no CPU fallback")
+    return torch.device(device or "cuda:0")
+
+
+def _stream(dev):
+    return C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+
+
+def eval_obs(kind, states, ref, device=None):
+    dev = _dev(device)
+    st = torch.as_tensor(np.asarray(states, dtype=np.float32)).to(dev).contiguous()
+    if st.dim() == 1:
+        st = st[None]
+    n, ns = st.shape
+    lib = L.lib()
+    D = lib.qd_obs_dim(kind, L.MODEL_LOAD if ns == 33 else L.MODEL_NOLOAD)
+    if D < 0:
+        raise NameError("name 'acc' is not defined")  # observation_wrappers.py:448
+    out = torch.empty((n, D), dtype=torch.float32, device=dev)
+    L.check(lib.qd_eval_obs(kind, ns, _ptr(st), L.double4(ref), _ptr(out), n, _stream(dev)))
+    return out
+
+
+def eval_reward(kind, states, actions, num_steps, ref, max_distance, device=None):
+    dev = _dev(device)
+    st = torch.as_tensor(np.asarray(states, dtype=np.float32)).to(dev).contiguous()
+    if st.dim() == 1:
+        st = st[None]
+    n, ns = st.shape
+    ac = torch.as_tensor(np.asarray(actions, dtype=np.float32)).to(dev).contiguous().reshape(n, 4)
+    ks = torch.as_tensor(np.asarray(num_steps, dtype=np.int32)).to(dev).contiguous().reshape(n)
+    out = torch.empty(n, dtype=torch.float32, device=dev)
+    lib = L.lib()
+    rc = lib.qd_eval_reward(kind, ns, _ptr(st), _ptr(ac), _ptr(ks), L.double4(ref), float(max_distance), _ptr(out), n,
+                            _stream(dev))
+    if rc == L.QD_ERR_UNSUPPORTED:
+        raise IndexError(L.last_error())  # params[4] on the 29-vector raises IndexError in the reference
+    L.check(rc)
+    return out
+
+
+def eval_truncated(states, num_steps, ref, max_distance, max_steps, device=None):
+    dev = _dev(device)
+    st = torch.as_tensor(np.asarray(states, dtype=np.float32)).to(dev).contiguous()
+    if st.dim() == 1:
+        st = st[None]
+    n, ns = st.shape
+    ks = torch.as_tensor(np.asarray(num_steps, dtype=np.int32)).to(dev).contiguous().reshape(n)
+    out = torch.empty(n, dtype=torch.uint8, device=dev)
+    L.check(L.lib().qd_eval_truncated(ns, _ptr(st), _ptr(ks), L.double4(ref), float(max_distance), int(max_steps),
+                                      _ptr(out), n, _stream(dev)))
+    return out
+
+
+def transform(which, x, in_dim, out_dim, device=None):
+    dev = _dev(device)
+    arr = np.asarray(x, dtype=np.float32)
+    single = arr.ndim == 1 or (which == L.TF_DCM2QUAT and arr.ndim == 2)
+    t = torch.as_tensor(arr.reshape(-1, in_dim)).to(dev).contiguous()
+    out = torch.empty((t.shape[0], out_dim), dtype=torch.float32, device=dev)
+    L.check(L.lib().qd_transform(which, _ptr(t), _ptr(out), t.shape[0], _stream(dev)))
+    res = out.cpu().numpy().astype(np.float64)
+    return res[0] if single else res

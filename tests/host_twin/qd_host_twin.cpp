@@ -1,0 +1,90 @@
+// Test-only harness: instantiates the product's templated math headers
+// (mujoco-drone_amd/csrc/qd_{model,dynamics,obsrew}.h) on the HOST, in float64
+// and float32, so the specialised body-frame derivation can be compared with the
+// general world-frame oracle at 1e-10 without a GPU.  Built by tests/ with g++;
+// never part of the product library, which has no CPU compute path.
+#include "qd_dynamics.h"
+#include "qd_model.h"
+
+using namespace qd;
+
+template <class T>
+static void run_step(int load, const double* model16, double* qpos, double* qvel, double* act, const double* ctrl,
+                     double h, int nstep, double* sensor) {
+  Model<T> M;
+  T* mp = reinterpret_cast<T*>(&M);
+  for (int i = 0; i < 16; i++) mp[i] = (T)model16[i];
+  State<T> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2];
+  s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = load ? qpos[7] : 0; s.th2 = load ? qpos[8] : 0;
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = load ? qvel[6] : 0; s.thd2 = load ? qvel[7] : 0;
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  T c[4];
+  for (int i = 0; i < 4; i++) c[i] = (T)(ctrl[i] < 0 ? 0 : (ctrl[i] > 1 ? 1 : ctrl[i]));
+  V3<T> acc = mk<T>(0, 0, 0);
+  for (int k = 0; k < nstep; k++)
+    acc = load ? substep<T, true>(M, s, c[0], c[1], c[2], c[3], (T)h) : substep<T, false>(M, s, c[0], c[1], c[2], c[3], (T)h);
+  qpos[0] = s.px; qpos[1] = s.py; qpos[2] = s.pz; qpos[3] = s.qw; qpos[4] = s.qx; qpos[5] = s.qy; qpos[6] = s.qz;
+  qvel[0] = s.vx; qvel[1] = s.vy; qvel[2] = s.vz; qvel[3] = s.wx; qvel[4] = s.wy; qvel[5] = s.wz;
+  if (load) { qpos[7] = s.th1; qpos[8] = s.th2; qvel[6] = s.thd1; qvel[7] = s.thd2; }
+  act[0] = s.a0; act[1] = s.a1; act[2] = s.a2; act[3] = s.a3;
+  sensor[0] = acc.x; sensor[1] = acc.y; sensor[2] = acc.z;
+}
+
+extern "C" {
+int twin_derive(const double raw[6], double out16[16]) {
+  bool load;
+  Model<double> M = derive_model(raw, &load);
+  const double* mp = reinterpret_cast<const double*>(&M);
+  for (int i = 0; i < 16; i++) out16[i] = mp[i];
+  return load ? 1 : 0;
+}
+double twin_round5(double x) { return round5(x); }
+void twin_step_f64(int load, const double* model16, double* qpos, double* qvel, double* act, const double* ctrl,
+                   double h, int nstep, double* sensor) {
+  run_step<double>(load, model16, qpos, qvel, act, ctrl, h, nstep, sensor);
+}
+void twin_step_f32(int load, const double* model16, double* qpos, double* qvel, double* act, const double* ctrl,
+                   double h, int nstep, double* sensor) {
+  run_step<float>(load, model16, qpos, qvel, act, ctrl, h, nstep, sensor);
+}
+}
+
+// ---- observation / reward twins (float64 instantiation of qd_obsrew.h) ----
+#include "qd_obsrew.h"
+extern "C" {
+int twin_obs(int kind, const double* s, int ns, const double* ref, double* out) {
+  int n = -1;
+#define CALL33(K) n = observe<double, 33, K>(s, ref, out)
+#define CALL29(K) n = observe<double, 29, K>(s, ref, out)
+  if (ns == 33) { QD_OBS_DISPATCH(kind, CALL33) } else { QD_OBS_DISPATCH(kind, CALL29) }
+  return n;
+}
+int twin_obs_dim(int kind, int ns) { return obs_dim(kind, ns); }
+double twin_reward(int kind, const double* s, const double* a, int k, const double* ref, double max_distance) {
+  return reward<double>(kind, s, a, k, ref, max_distance);
+}
+int twin_truncated(const double* s, const double* ref, int k, double max_distance, int max_steps) {
+  return truncated<double>(s, ref, k, max_distance, max_steps) ? 1 : 0;
+}
+int twin_drone_state(int load, const double* qpos, const double* qvel, const double* sens, const double* act,
+                     const double* ref, const double* par, double* out) {
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = load ? qpos[7] : 0; s.th2 = load ? qpos[8] : 0;
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = load ? qvel[6] : 0; s.thd2 = load ? qvel[7] : 0;
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  V3<double> acc = mk<double>(sens[0], sens[1], sens[2]);
+  if (load) { drone_state<double, true>(s, acc, ref, par, out); return 33; }
+  drone_state<double, false>(s, acc, ref, par, out);
+  return 29;
+}
+void twin_simple_obs(const double* qpos, double* out) {
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  simple_obs<double>(s, out);
+}
+}

@@ -1,0 +1,466 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the
+C ABI (include/qd.h) via the Python mirrors, against the CPU oracle on the same seeded
+inputs and against the golden vectors captured from the reference's Python.
+
+Tolerances (float32 device arithmetic vs float64 oracle):
+  pure functions (obs / reward / attitude)   5e-5 absolute on O(1..30) values
+  one physics step                            2e-5 absolute
+  200-step trajectories                       1e-4 relative (the BASELINE.json target), see test
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def qd():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import mujoco_drone_amd  # noqa: F401
+    from mujoco_drone_amd import _lib
+    from mujoco_drone_amd.environments import _device
+    _lib.lib()  # fail loudly if the HIP library is missing
+    return types_ns(_lib=_lib, dev=_device)
+
+
+def types_ns(**kw):
+    import types
+    return types.SimpleNamespace(**kw)
+
+
+def make_cfg(L, n, load=True, obs="LocalFrameRPYParamsEnv", reward="distance_energy_reward", frame_skip=1, h=0.01,
+             ctrl_map=1, term=0, start=0, random_params=0, auto_reset=0, seed=42, max_steps=512, max_distance=4.0,
+             ref=(0, 0, 15, 0), start_pos=(0, 0, 15, 0), difficulty=1.0, sdiff=0.4):
+    c = L.QdConfig()
+    c.num_envs, c.model = n, int(load)
+    c.obs_kind, c.reward_kind = L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(reward)
+    c.frame_skip, c.max_steps, c.ctrl_map, c.term_kind = frame_skip, max_steps, ctrl_map, term
+    c.random_start, c.random_params, c.auto_reset, c.per_env_reference = start, random_params, auto_reset, 0
+    c.timestep, c.max_distance = h, max_distance
+    c.reference[:] = ref
+    c.start_pos[:] = start_pos
+    c.max_pos_offset = sdiff * 2
+    c.angle_var[:] = [0.0, 0.0]
+    c.vel_var[:] = [sdiff] * 3
+    c.ang_vel_var[:] = [sdiff] * 3
+    c.pend_rp_var[:] = [sdiff * 0.5] * 2
+    c.pend_vel_var[:] = [sdiff * 0.5] * 2
+    c.param_center[:] = [1, 0.17, 7, 0.01, 1.2, 0.3]
+    c.param_width[:] = [0.1, 0.02, 1, 0.0025, 0.2, 0.05]
+    c.param_difficulty = difficulty
+    c.seed = seed
+    return c
+
+
+CENTER = np.array([1, 0.17, 7, 0.01, 1.2, 0.3])
+WIDTH = np.array([0.1, 0.02, 1, 0.0025, 0.2, 0.05])
+
+
+def rand_raw(rng, n, load):
+    raw = CENTER + rng.uniform(-1, 1, (n, 6)) * WIDTH
+    if not load:
+        raw[:, 4:] = 0
+    return raw
+
+
+def rand_state(rng, n, load):
+    nq, nv = (9, 8) if load else (7, 6)
+    qpos = np.zeros((n, nq)); qvel = rng.normal(scale=1.0, size=(n, nv))
+    qpos[:, :3] = np.array([0, 0, 15]) + rng.normal(scale=1.0, size=(n, 3))
+    q = rng.normal(size=(n, 4)); qpos[:, 3:7] = q / np.linalg.norm(q, axis=1, keepdims=True)
+    if load:
+        qpos[:, 7:] = rng.normal(scale=0.5, size=(n, 2))
+    act = rng.uniform(0, 1, (n, 4))
+    return qpos, qvel, act
+
+
+# ------------------------------------------------------------------ pure functions vs golden
+def test_transform_vs_golden(qd, golden):
+    from mujoco_drone_amd.environments import transformation as tr
+    np.testing.assert_allclose(tr.mujoco_quat2DCM(golden["tr_quat"]), golden["tr_quat2dcm"], atol=2e-6)
+    rpy = tr.mujoco_quat2rpy(golden["tr_quat"])
+    ok = np.abs(np.abs(golden["tr_quat2rpy"][:, 1]) - np.pi / 2) > 1e-3
+    np.testing.assert_allclose(rpy[ok], golden["tr_quat2rpy"][ok], atol=2e-5)
+    np.testing.assert_allclose(tr.mujoco_rpy2quat(golden["tr_rpy"]), golden["tr_rpy2quat"], atol=2e-6)
+    np.testing.assert_allclose(tr.mujoco_pendulumrp2quat(golden["tr_prp"]), golden["tr_pendrp2quat"], atol=2e-6)
+    np.testing.assert_allclose(tr.mujoco_DCM2quat(golden["tr_quat2dcm"].reshape(-1, 9)), golden["tr_dcm2quat"], atol=2e-6)
+    np.testing.assert_allclose(tr.mujoco_rpy2quat([0.1, -0.2, 0.3]), [0.98185617, 0.06407135, -0.09115755, 0.1534393],
+                               atol=1e-6)
+
+
+OBS = ["GlobalFrameRPYEnv", "LocalFramePRYEnv", "LocalFrameFullStateEnv", "LocalFrameFullStateZvecEnv",
+       "LocalFramePRYaccEnv", "LocalFramePRYParamsEnv", "LocalFramePRYaccParamsEnv", "LocalFrameRPYParamsEnv",
+       "LocalFrameRPYFakeParamsEnv", "LocalFrameRPYEnv", "LocalFramePRYaccNoPendEnv", "LocalFrameRmParamsEnv",
+       "LocalFrameZvecEnv"]
+
+
+@pytest.mark.parametrize("tag", ["33", "29"])
+def test_obs_variants_vs_golden(qd, golden, tag):
+    for name in OBS:
+        got = qd.dev.eval_obs(qd._lib.OBS_KINDS.index(name), golden["st" + tag], golden["st_ref"]).cpu().numpy()
+        want = golden["obs%s_%s" % (tag, name)]
+        assert got.shape == want.shape, name
+        np.testing.assert_allclose(got, want, atol=5e-5, err_msg=name)
+    with pytest.raises(NameError):
+        qd.dev.eval_obs(qd._lib.OBS_KINDS.index("LocalFramePRYaccParamsNoPendEnv"), golden["st33"], golden["st_ref"])
+
+
+REWARDS = ["default_reward_fcn", "distance_reward_fcn", "distance_energy_reward",
+           "distance_energy_reward_pendulum_angle", "distance_energy_reward_pendulum_angle2",
+           "distance_energy_reward_pendulum_angle3", "distance_energy_reward_pendulum_en",
+           "distance_energy_reward_pendulum_en2", "distance_energy_reward_pendulum_en3",
+           "distance_energy_reward_pendulum_en4", "distance_time_energy_reward", "reward_1", "reward_pendulum_dist",
+           "reward_pendulumDistHeading", "reward_2", "reward_2_penergy", "reward_3"]
+
+
+def test_rewards_vs_golden(qd, golden):
+    S, A, K, ref = golden["st33"], golden["st_actions"], golden["st_num_steps"], golden["st_ref"]
+    for name in REWARDS:
+        got = qd.dev.eval_reward(qd._lib.REWARD_KINDS.index(name), S, A, K, ref, 4.0).cpu().numpy()
+        want = golden["rew_" + name]
+        np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-4, err_msg=name)
+    for name in REWARDS[:6] + ["distance_time_energy_reward", "reward_1"]:
+        got = qd.dev.eval_reward(qd._lib.REWARD_KINDS.index(name), golden["st29"], A, K, ref, 4.0).cpu().numpy()
+        np.testing.assert_allclose(got, golden["rew29_" + name], rtol=2e-5, atol=2e-4, err_msg=name)
+    with pytest.raises(IndexError):
+        qd.dev.eval_reward(qd._lib.REWARD_KINDS.index("reward_2"), golden["st29"], A, K, ref, 4.0)
+    tr = qd.dev.eval_truncated(S, K, ref, 4.0, 512).cpu().numpy().astype(bool)
+    assert list(tr) == list(golden["trunc33"])
+
+
+def test_reward_objects_callable_like_reference(qd, golden):
+    from mujoco_drone_amd.environments import rewards
+    import types
+    env = types.SimpleNamespace(reference=golden["st_ref"], max_distance=4.0, max_steps=512)
+    i = 5
+    r = rewards.distance_energy_reward(env, golden["st33"][i], golden["st_actions"][i], int(golden["st_num_steps"][i]))
+    assert abs(r - golden["rew_distance_energy_reward"][i]) < 1e-4
+
+
+# ------------------------------------------------------------------ model constants
+@pytest.mark.parametrize("load", [True, False])
+def test_model_constants_vs_oracle(qd, orc, load):
+    rng = np.random.default_rng(3)
+    n = 300
+    raw = rand_raw(rng, n, load)
+    raw[0] = [1.35, 0.15, 7.5, 0.015, 1.2 * load, 0.3 * load]
+    env = qd.dev.DeviceEnv(make_cfg(qd._lib, n, load=load, obs="BaseDroneEnv", reward="default_reward_fcn"))
+    env.set_params(raw)
+    np.testing.assert_array_equal(env.get_params().cpu().numpy(), raw)
+    mc = {k: v.cpu().numpy().astype(np.float64) for k, v in env.model_constants().items()}
+    for i in range(n):
+        m = orc.build_model(raw[i])
+        want = dict(m0=m.m0, c0z=m.c0[2], I0x=m.I0full[0], I0y=m.I0full[1], I0z=m.I0full[2], rot=m.rotor[1][0],
+                    gearF=m.gearF, gearT=m.gearT[0], inv_tau=1 / m.tau, m2=m.m2, lc=m.lc, I2t=m.I2[0], I2a=m.I2[2])
+        for k, v in want.items():
+            assert abs(mc[k][i] - v) <= 2e-7 * abs(v) + 1e-30, (i, k, mc[k][i], v)
+
+
+# ------------------------------------------------------------------ physics: one step
+@pytest.mark.parametrize("load,frame_skip,h", [(True, 1, 0.01), (False, 1, 0.01), (False, 2, 0.001), (True, 3, 0.005)])
+def test_single_step_vs_oracle(qd, orc, load, frame_skip, h):
+    rng = np.random.default_rng(11)
+    n = 512
+    raw = rand_raw(rng, n, load)
+    qpos, qvel, act = rand_state(rng, n, load)
+    actions = rng.uniform(-0.05, 1.05, (n, 4))
+    env = qd.dev.DeviceEnv(make_cfg(qd._lib, n, load=load, obs="BaseDroneEnv", reward="default_reward_fcn",
+                                    frame_skip=frame_skip, h=h))
+    env.set_params(raw)
+    env.set_state(qpos, qvel, act)
+    env.step(actions.astype(np.float32))
+    gq, gv, ga, gs, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(gk == 1)
+    worst = 0
+    for i in range(n):
+        m = orc.build_model(raw[i])
+        ctrl = 0.1 + 0.9 * actions[i].astype(np.float32).astype(np.float64)
+        oq, ov, oa, osens = orc.step(m, h, frame_skip, qpos[i].astype(np.float32), qvel[i].astype(np.float32),
+                                     act[i].astype(np.float32), ctrl)
+        for g, o, tol in ((gq[i], oq, 2e-5), (gv[i], ov, 5e-5), (ga[i], oa, 1e-5), (gs[i], osens, 2e-3)):
+            err = np.max(np.abs(g - o) / np.maximum(1.0, np.abs(o)))
+            worst = max(worst, err)
+            assert err < tol, (i, g, o)
+    print("single-step worst relative error", worst)
+
+
+# ------------------------------------------------------------------ trajectories (BASELINE configs 1-3)
+def _trajectory(qd, orc, load, n, steps, frame_skip, h, ctrl_map, actions_fn, raw, qpos0, qvel0, obs, reward, term,
+                ref, max_distance=4.0):
+    L = qd._lib
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs=obs, reward=reward, frame_skip=frame_skip, h=h,
+                                    ctrl_map=ctrl_map, term=term, ref=ref, max_steps=10 ** 6, max_distance=max_distance))
+    env.set_params(raw)
+    env.set_state(qpos0, qvel0, np.zeros((n, 4)))
+    ob = orc.Batch(raw, load, L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(reward), h, frame_skip, ctrl_map, ref,
+                   max_distance, 10 ** 6)
+    ob.qpos[:], ob.qvel[:] = qpos0, qvel0
+    worst = dict(qpos=0.0, qvel=0.0, act=0.0, obs=0.0, rew=0.0)
+    for t in range(steps):
+        a = actions_fn(t).astype(np.float32)
+        o, r, tr = env.step(a)
+        oo, orr, otr = ob.step(a.astype(np.float64), threads=8)
+        if t % 20 == 19 or t == steps - 1:
+            gq, gv, ga, gs, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+            for k, g, w in (("qpos", gq, ob.qpos), ("qvel", gv, ob.qvel), ("act", ga, ob.act)):
+                worst[k] = max(worst[k], float(np.max(np.abs(g - w) / np.maximum(1.0, np.abs(w)))))
+            worst["obs"] = max(worst["obs"], float(np.max(np.abs(o.cpu().numpy() - oo) / np.maximum(1.0, np.abs(oo)))))
+            worst["rew"] = max(worst["rew"], float(np.max(np.abs(r.cpu().numpy() - orr) / np.maximum(1.0, np.abs(orr)))))
+    return worst
+
+
+def test_config1_simpledrone_hover_200_steps(qd, orc):
+    """BASELINE config 1: SimpleDrone, 1 env, constant throttle 0.7, 200 steps (test_env.py:10-12)"""
+    raw = np.array([[1.35, 0.15, 7.5, 0.015, 0, 0]])
+    q0 = np.array([[0, 0, 1, 1, 0, 0, 0.0]]); v0 = np.zeros((1, 6))
+    w = _trajectory(qd, orc, False, 1, 200, 2, 0.001, 0, lambda t: np.full((1, 4), 0.7), raw, q0, v0, "SimpleDrone",
+                    "simple_drone_reward", 1, (0, 0, 1, 0))
+    print("config 1 divergence", w)
+    assert max(w["qpos"], w["qvel"], w["act"]) < 1e-4
+
+
+@pytest.mark.parametrize("cfg", ["config2_noload", "config3_load"])
+def test_200_step_state_divergence(qd, orc, cfg):
+    """BASELINE configs 2/3 at parity-test size: 256 envs, 200 steps of random rotor actions, float32 HIP
+    vs float64 oracle.  Target from BASELINE.json: <= 1e-4 relative over qpos, qvel, act."""
+    rng = np.random.default_rng(5)
+    n, steps = 256, 200
+    if cfg == "config2_noload":
+        raw = np.tile([1.35, 0.15, 7.5, 0.015, 0, 0], (n, 1))
+        q0 = np.tile([0, 0, 1, 1, 0, 0, 0.0], (n, 1)); v0 = np.zeros((n, 6))
+        acts = rng.uniform(0.5, 1.0, (steps, n, 4))
+        w = _trajectory(qd, orc, False, n, steps, 2, 0.001, 0, lambda t: acts[t], raw, q0, v0, "SimpleDrone",
+                        "simple_drone_reward", 1, (0, 0, 1, 0))
+    else:
+        raw = rand_raw(rng, n, True)
+        q0, v0, _ = rand_state(rng, n, True)
+        q0[:, 3:7] = [1, 0, 0, 0]; v0 *= 0.4; q0[:, 7:] *= 0.4
+        acts = rng.uniform(0, 1, (steps, n, 4))
+        w = _trajectory(qd, orc, True, n, steps, 1, 0.01, 1, lambda t: acts[t], raw, q0, v0, "LocalFrameRPYParamsEnv",
+                        "distance_energy_reward", 0, (0, 0, 15, 0), max_distance=1e9)
+    print(cfg, "divergence after 200 steps", w)
+    assert max(w["qpos"], w["qvel"], w["act"]) < 1e-4, w
+
+
+# ------------------------------------------------------------------ fused obs / reward / truncation from the step
+@pytest.mark.parametrize("obs,reward,load", [("LocalFrameRPYParamsEnv", "distance_energy_reward", True),
+                                             ("LocalFrameFullStateEnv", "distance_energy_reward_pendulum_en4", True),
+                                             ("LocalFrameFullStateZvecEnv", "reward_3", True),
+                                             ("LocalFrameRmParamsEnv", "reward_2_penergy", True),
+                                             ("BaseDroneEnv", "reward_1", True),
+                                             ("LocalFramePRYaccNoPendEnv", "distance_energy_reward", False),
+                                             ("BaseDroneEnv", "default_reward_fcn", False)])
+def test_step_outputs_vs_oracle(qd, orc, obs, reward, load):
+    rng = np.random.default_rng(21)
+    n, L = 200, qd._lib
+    raw = rand_raw(rng, n, load)
+    qpos, qvel, act = rand_state(rng, n, load)
+    qpos[:, :3] = np.array([0, 0, 15]) + rng.normal(scale=2.2, size=(n, 3))  # some beyond max_distance
+    ref = (0.2, -0.1, 15.0, 0.4)
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs=obs, reward=reward, ref=ref, max_steps=3))
+    env.set_params(raw)
+    env.set_state(qpos, qvel, act)
+    ob = orc.Batch(raw, load, L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(reward), 0.01, 1, 1, ref, 4.0, 3)
+    ob.qpos[:], ob.qvel[:], ob.act[:] = (qpos.astype(np.float32), qvel.astype(np.float32), act.astype(np.float32))
+    for t in range(3):
+        a = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+        o, r, tr = env.step(a)
+        oo, orr, otr = ob.step(a.astype(np.float64))
+        o, r, tr = o.cpu().numpy(), r.cpu().numpy(), tr.cpu().numpy()
+        assert o.shape == oo.shape
+        np.testing.assert_allclose(o, oo, rtol=1e-4, atol=3e-3 if "acc" in obs or "Full" in obs or obs == "BaseDroneEnv" else 2e-4)
+        np.testing.assert_allclose(r, orr, rtol=2e-4, atol=2e-3)
+        # truncation may differ only where the distance is within float32 noise of the threshold
+        d = np.linalg.norm(ob.qpos[:, :3] - np.array(ref[:3]), axis=1)
+        sure = np.abs(d - 4.0) > 1e-4
+        assert np.array_equal(tr.astype(bool)[sure], otr.astype(bool)[sure])
+    assert tr.all()  # max_steps = 3 reached
+
+
+# ------------------------------------------------------------------ reset sampling / parameter randomisation
+@pytest.mark.parametrize("load", [True, False])
+def test_reset_sampling_vs_oracle(qd, orc, load):
+    n, seed, L = 257, 1234, qd._lib
+    cfgc = make_cfg(L, n, load=load, obs="BaseDroneEnv", reward="default_reward_fcn", start=1, seed=seed, sdiff=0.4)
+    cfgc.angle_var[:] = [0.3, 0.2]
+    env = qd.dev.DeviceEnv(cfgc)
+    ocfg = orc.sample_cfg(load, 1, list(cfgc.start_pos), cfgc.max_pos_offset, list(cfgc.angle_var), list(cfgc.vel_var),
+                          list(cfgc.ang_vel_var), list(cfgc.pend_rp_var), list(cfgc.pend_vel_var))
+    for episode in range(2):
+        env.reset()
+        gq, gv, ga, gs, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+        assert np.all(gk == 0)
+        for i in range(n):
+            oq, ov = orc.sample_state_philox(ocfg, seed, i, episode)
+            np.testing.assert_allclose(gq[i], oq, atol=2e-5)
+            np.testing.assert_allclose(gv[i], ov, atol=2e-5)
+    # reset_at advances only that env's episode counter
+    env.reset_at(7)
+    gq2 = env.get_state()[0].cpu().numpy().astype(np.float64)
+    oq, _ = orc.sample_state_philox(ocfg, seed, 7, 2)
+    np.testing.assert_allclose(gq2[7], oq, atol=2e-5)
+    np.testing.assert_array_equal(np.delete(gq2, 7, axis=0), np.delete(gq, 7, axis=0))
+    # masked reset
+    mask = np.zeros(n, dtype=np.uint8); mask[[3, 100]] = 1
+    env.reset(mask)
+    gq3 = env.get_state()[0].cpu().numpy().astype(np.float64)
+    assert not np.allclose(gq3[3], gq2[3]) and not np.allclose(gq3[100], gq2[100])
+    np.testing.assert_array_equal(np.delete(gq3, [3, 100], axis=0), np.delete(gq2, [3, 100], axis=0))
+    with pytest.raises(AssertionError):
+        env.reset_at(n)
+
+
+def test_reset_sampling_statistics(qd):
+    """distributional check of sample_state at full size (4096 envs): uniform-in-ball offset, clipped normals"""
+    n, L = 4096, qd._lib
+    c = make_cfg(L, n, load=True, obs="BaseDroneEnv", reward="default_reward_fcn", start=1, seed=7, sdiff=0.4)
+    env = qd.dev.DeviceEnv(c)
+    env.reset()
+    q, v = [x.cpu().numpy().astype(np.float64) for x in env.get_state()[:2]]
+    r = np.linalg.norm(q[:, :3] - np.array([0, 0, 15]), axis=1)
+    assert r.max() <= 0.8 + 1e-5
+    assert abs(np.mean((r / 0.8) ** 3) - 0.5) < 0.03          # r^3 uniform
+    assert np.abs(v[:, :6]).max() <= 0.8 + 1e-6                 # clipped at 2 sigma
+    assert abs(np.std(v[:, 0]) - 0.4 * 0.8796) < 0.02           # std of a normal clipped at 2 sigma
+    assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1, atol=1e-6)
+    yaw = 2 * np.arctan2(q[:, 6], q[:, 3])
+    assert abs(np.mean(np.cos(yaw))) < 0.05 and abs(np.mean(np.sin(yaw))) < 0.05
+
+
+def test_param_randomisation_vs_oracle(qd, orc):
+    n, seed, L = 300, 99, qd._lib
+    for load in (True, False):
+        env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs="BaseDroneEnv", reward="default_reward_fcn", random_params=1,
+                                        seed=seed, difficulty=0.7))
+        for regen in range(3):
+            got = env.get_params().cpu().numpy()
+            for i in range(0, n, 7):
+                want = orc.gen_params_philox(seed, i, regen, CENTER, WIDTH, 0.7, True, load)
+                np.testing.assert_allclose(got[i], want, rtol=1e-14, atol=1e-16)
+            assert np.all(np.abs(got[:, :4] - CENTER[:4]) <= WIDTH[:4] * 0.7 + 1e-12)
+            env.randomize_params()
+        # regen zeroes the activations (fresh MjData)
+        assert float(env.get_state()[2].abs().max()) == 0.0
+
+
+# ------------------------------------------------------------------ rollout kernel, auto reset, size independence
+@pytest.mark.parametrize("load", [True, False])
+def test_rollout_equals_steps(qd, load):
+    rng = np.random.default_rng(8)
+    n, T, L = 1000, 12, qd._lib
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=load, start=1, random_params=1, auto_reset=1, max_steps=5, seed=3))
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    acts = torch.as_tensor(rng.uniform(0, 1, (T, n, 4)).astype(np.float32)).cuda()
+    O, R, Tr = a.rollout(acts)
+    for t in range(T):
+        o, r, tr = b.step(acts[t])
+        np.testing.assert_allclose(O[t].cpu().numpy(), o.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(R[t].cpu().numpy(), r.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        assert torch.equal(Tr[t], tr)
+    assert int(Tr[4].sum()) == n and int(Tr[9].sum()) == n      # max_steps = 5 -> every env truncates at t = 4, 9
+    for x, y in zip(a.get_state(), b.get_state()):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-5)
+
+
+def test_auto_reset_resamples_truncated_envs(qd, orc):
+    n, seed, L = 128, 17, qd._lib
+    c = make_cfg(L, n, load=True, obs="BaseDroneEnv", reward="default_reward_fcn", start=1, auto_reset=1, max_steps=2, seed=seed)
+    env = qd.dev.DeviceEnv(c)
+    env.reset()
+    a = np.full((n, 4), 0.4, dtype=np.float32)
+    _, _, t1 = env.step(a)
+    assert int(t1.sum()) == 0
+    obs, _, t2 = env.step(a)
+    assert int(t2.sum()) == n
+    gq, gv, _, _, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(gk == 0)
+    ocfg = orc.sample_cfg(True, 1, list(c.start_pos), c.max_pos_offset, list(c.angle_var), list(c.vel_var),
+                          list(c.ang_vel_var), list(c.pend_rp_var), list(c.pend_vel_var))
+    for i in range(0, n, 9):
+        oq, ov = orc.sample_state_philox(ocfg, seed, i, 1)  # episode 0 was the explicit reset
+        np.testing.assert_allclose(gq[i], oq, atol=2e-5)
+        np.testing.assert_allclose(obs[i, :3].cpu().numpy(), oq[:3], atol=2e-5)  # obs row = first obs of the new episode
+
+
+def test_full_size_independence_and_invariants(qd):
+    """BASELINE size (4096 envs): env i's trajectory must not depend on the batch it is in (one env per lane, no
+    cross-lane traffic), quaternions stay unit, activations stay in [0,1], nothing is NaN."""
+    rng = np.random.default_rng(2)
+    L, T = qd._lib, 50
+    big = qd.dev.DeviceEnv(make_cfg(L, 4096, load=True, start=1, random_params=1, seed=5))
+    small = qd.dev.DeviceEnv(make_cfg(L, 100, load=True, start=1, random_params=1, seed=5))
+    big.reset(); small.reset()
+    acts = rng.uniform(0, 1, (T, 4096, 4)).astype(np.float32)
+    for t in range(T):
+        ob, rb, tb = big.step(acts[t])
+        os_, rs, ts = small.step(acts[t, :100])
+        assert torch.equal(ob[:100], os_) and torch.equal(rb[:100], rs) and torch.equal(tb[:100], ts)
+    q, v, a, s, k = big.get_state()
+    assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(s).all()
+    assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(4096, device=q.device), atol=1e-5)
+    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6
+    assert torch.all(k == T)
+
+
+# ------------------------------------------------------------------ Python surface (reference API behaviour)
+def test_vector_env_surface(qd):
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    cfg = dict(base_config)
+    cfg.update(num_drones=8, reward_fcn=distance_energy_reward, max_steps=4, regen_env_at_steps=6, param_difficulty=1,
+               state_difficulty=0.2)
+    env = LocalFrameRPYParamsEnv(cfg)
+    assert env.num_envs == 8 and env.observation_space.shape == (22,) and env.action_space.shape == (4,)
+    obs, infos = env.vector_reset()
+    assert len(obs) == 8 and obs[0].shape == (22,) and obs[0].dtype == np.float64 and infos == [{}] * 8
+    assert len(env.states) == 8 and env.states[0].shape == (33,)
+    p0 = env.drone_params
+    assert list(p0[0].keys()) == ['mass', 'arm_len', 'motor_force', 'motor_tau', 'pendulum_len', 'weight_mass']
+    with pytest.raises(ValueError, match="Action dimension mismatch"):
+        env.vector_step([np.zeros(4)] * 7)
+    for t in range(1, 7):
+        o, r, d, tr, info = env.vector_step([np.full(4, 0.45)] * 8)
+        assert len(o) == 8 and len(r) == 8 and d == [False] * 8 and len(info) == 8 and isinstance(r[0], float)
+        if t == 4:
+            assert tr == [True] * 8                       # max_steps reached: truncated, never terminated
+            stale = o[3].copy()
+            ob, inf = env.reset_at(3)                     # QUIRK C-1: stale pre-reset observation
+            np.testing.assert_array_equal(ob, stale)
+            assert env.num_steps[3] == 0
+        if t == 6:
+            assert isinstance(tr, np.ndarray) and tr.all()  # regen: ndarray of ones (QUIRK C-5)
+            assert env.total_steps == 0
+            assert env.drone_params[0] != p0[0]             # new parameters
+    assert np.allclose(env.states[0][23:27], [0, 0, 15, 0])
+    env.reference = [1.0, 0, 15, 0.5]
+    o, *_ = env.vector_step([np.full(4, 0.45)] * 8)
+    assert np.allclose(env.states[0][23:27], [1.0, 0, 15, 0.5])
+    qpos, qvel = env.data.qpos.copy(), env.data.qvel.copy()
+    assert qpos.shape == (72,) and qvel.shape == (64,)
+    env.set_state(qpos, qvel)
+    np.testing.assert_allclose(env.data.qpos, qpos, atol=1e-6)
+
+
+def test_simple_drone_surface(qd, orc):
+    from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
+    env = SimpleDrone(num_drones=1)
+    ob = env.reset()
+    assert ob.shape == (6,) and np.allclose(ob[:3], [0, 0, 1])
+    m = orc.build_model([1.35, 0.15, 7.5, 0.015, 0, 0])
+    d = env.data
+    qpos, qvel, act = d.qpos.copy(), d.qvel.copy(), d.act.copy()
+    assert np.all(act == 0)
+    for _ in range(20):
+        ob, rew, term, info = env.step(np.ones(4) * 0.7)
+        qpos, qvel, act, _ = orc.step(m, 0.001, 2, qpos, qvel, act, np.ones(4) * 0.7)
+    np.testing.assert_allclose(ob, orc.simple_obs(qpos), atol=2e-5)
+    assert abs(rew - (0.1 - np.linalg.norm(qpos[:3] - [0, 0, 1]))) < 1e-5 and term is False and info == {}
+    with pytest.raises(ValueError, match="Action dimension mismatch"):
+        env.step(np.ones(3))
