@@ -43,6 +43,19 @@ def make_env(kind, n, seed, device, auto_reset=True):
     raise ValueError(kind)
 
 
+def cpu_share():
+    """host threads this process may really use: cgroup quota if set, else affinity, capped at 16
+    (the CPU share of a one-GPU box; an uncapped count oversubscribes a shared host)"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return int(os.environ.get("QD_CPU_THREADS", min(n, 16)))
+
+
 def cpu_baseline(seconds_target=12.0):
     """the oracle (C float64 port of the same step) on the host cores, config 3 at 4096 envs"""
     import numpy as np
@@ -55,7 +68,7 @@ def cpu_baseline(seconds_target=12.0):
     b = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameRPYParamsEnv"), L.REWARD_KINDS.index("distance_energy_reward"),
                   0.01, 1, 1, [0, 0, 15, 0], 4.0, 1024)
     b.qpos[:, 2] = 15.0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = cpu_share()
     acts = rng.uniform(0, 1, (8, n, 4))
     b.step(acts[0], threads=cores)
     t0 = time.perf_counter()

@@ -94,6 +94,9 @@ def lib():
             raise ImportError(
                 "libqd.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'` or "
                 "`python -m mujoco_drone_amd.build`; there is no CPU fallback." % LIB)
+        # torch first: its bundled HIP runtime must be the one already in the process when libqd.so
+        # resolves libamdhip64 (loading the system copy first leaves two runtimes fighting for the device)
+        import torch  # noqa: F401
         handle = C.CDLL(LIB)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the library does not export it

@@ -10,7 +10,7 @@ import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
-LIB = os.path.join(PKG_DIR, "libqd.so")
+LIB = os.environ.get("QD_LIB") or os.path.join(PKG_DIR, "libqd.so")  # QD_LIB: diagnostic builds only
 SOURCES = ["qd_kernels.hip"]
 HEADERS = ["qd_math.h", "qd_model.h", "qd_dynamics.h", "qd_obsrew.h", "qd_rng.h", os.path.join("..", "..", "include", "qd.h")]
 ARCH = "gfx950"

@@ -23,6 +23,15 @@
 //   * what is left is one symmetric 3x3 factorisation (LDL^T) shared by the
 //     explicit solve (sensor) and the damping-implicit solve (integration), then
 //     two 2x2 solves.
+//
+// Precision: state, trigonometry, fluid forces and integration are float32 (T).  The
+// velocity-product terms, the inertia assembly about the system COM (sums of
+// non-negative terms, no cancellation) and the solves of the load model run in HP:
+// float64 on the device.  The load hangs 1.2 m below a 0.01 kg m^2 airframe, so the 3x3
+// inertia has a condition number of ~60 and float32 algebra there costs a factor ~15 in
+// 200-step trajectory divergence (measured: 5e-4 -> 3e-5 worst case over 128 envs with
+// random rotor commands, against the float64 oracle); CDNA4 issues f64 FMAs at half the
+// packed-f32 rate, i.e. at the rate of the scalar f32 FMAs this per-lane code uses anyway.
 #pragma once
 #include "qd_math.h"
 #include "qd_model.h"
@@ -47,27 +56,22 @@ struct Accel {
   T thdd1, thdd2;
 };
 
-// inertia-box fluid wrench for a body with box dims (bx,by,bz), local angular
-// velocity w and local COM velocity v (both in the body's inertial-frame axes)
+// the float64 type used for the algebra core of the load model
+template <class T> struct HighPrec { using type = double; };
+
+// inertia-box fluid wrench from precomputed coefficients (qd_model.h): local angular
+// velocity w and local COM velocity v, both in the body's inertial-frame axes
 template <class T>
-QD_HD void fluid(T bx, T by, T bz, V3<T> w, V3<T> v, V3<T>* f, V3<T>* tq) {
-  const T rho = T(Const::density), mu = T(Const::viscosity), pi = T(3.14159265358979323846);
-  const T d = (bx + by + bz) * T(1.0 / 3.0);
-  const T kang = pi * d * d * d * mu, klin = T(3) * pi * d * mu;
-  const T bx2 = bx * bx, by2 = by * by, bz2 = bz * bz;
-  const T bx4 = bx2 * bx2, by4 = by2 * by2, bz4 = bz2 * bz2;
-  f->x = -(klin + T(0.5) * rho * by * bz * qabs(v.x)) * v.x;
-  f->y = -(klin + T(0.5) * rho * bx * bz * qabs(v.y)) * v.y;
-  f->z = -(klin + T(0.5) * rho * bx * by * qabs(v.z)) * v.z;
-  tq->x = -(kang + rho * bx * (by4 + bz4) * T(1.0 / 64.0) * qabs(w.x)) * w.x;
-  tq->y = -(kang + rho * by * (bx4 + bz4) * T(1.0 / 64.0) * qabs(w.y)) * w.y;
-  tq->z = -(kang + rho * bz * (bx4 + by4) * T(1.0 / 64.0) * qabs(w.z)) * w.z;
+QD_HD void fluid(T klin, T kang, T qlx, T qly, T qlz, T qax, T qay, T qaz, V3<T> w, V3<T> v, V3<T>* f, V3<T>* tq) {
+  f->x = -(klin + qlx * qabs(v.x)) * v.x;
+  f->y = -(klin + qly * qabs(v.y)) * v.y;
+  f->z = -(klin + qlz * qabs(v.z)) * v.z;
+  tq->x = -(kang + qax * qabs(w.x)) * w.x;
+  tq->y = -(kang + qay * qabs(w.y)) * w.y;
+  tq->z = -(kang + qaz * qabs(w.z)) * w.z;
 }
 
-template <class T>
-QD_HD T boxdim(T Ij, T Ik, T Ii, T mass) {  // sqrt(6 (Ij + Ik - Ii) / mass)
-  return qsqrt(qmax(T(1e-15), Ij + Ik - Ii) / mass * T(6));
-}
+template <class A, class B> QD_HD V3<A> cvt(V3<B> v) { return mk<A>(A(v.x), A(v.y), A(v.z)); }
 
 // forward dynamics at the current state.
 //   ex  : accelerations with damping explicit (what MuJoCo stores in qacc; feeds the sensor)
@@ -75,177 +79,177 @@ QD_HD T boxdim(T Ij, T Ik, T Ii, T mass) {  // sqrt(6 (Ij + Ik - Ii) / mass)
 //   acc : accelerometer reading (site frame = body frame)
 template <class T, bool LOAD>
 QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Accel<T>* im, V3<T>* acc) {
+  using HP = typename HighPrec<T>::type;
   // attitude (MuJoCo normalises the stored quaternion before use)
-  T qn = T(1) / qsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
   const M3<T> R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
   const V3<T> w = mk<T>(s.wx, s.wy, s.wz);
   const V3<T> vb = mulT(R, mk<T>(s.vx, s.vy, s.vz));  // origin velocity in body axes
   const T g = T(Const::gravity);
   const V3<T> gt = mk<T>(g * R.m20, g * R.m21, g * R.m22);
 
-  // ---- body 0 -------------------------------------------------------------
-  const V3<T> c0 = mk<T>(T(0), T(0), M.c0z);
-  const V3<T> wxc0 = cross(w, c0);
-  const V3<T> ac0 = gt + cross(w, wxc0);
-  const V3<T> F0 = M.m0 * ac0;
-  const V3<T> N0 = cross(w, mk<T>(M.I0x * w.x, M.I0y * w.y, M.I0z * w.z));
   // rotors (env_gen.py:53-64): thrust along body z at (+-rot, +-rot, 0), yaw reaction +-gearT
   const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
   const V3<T> fT = mk<T>(T(0), T(0), f0 + f1 + f2 + f3);
-  const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3),
-                         M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
-  // fluid drag on the core, evaluated in body axes (see qd_model.h on the principal frame)
+  const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
+  // fluid drag on the core, evaluated in body axes (see qd_model.h on the principal frame);
+  // COM at (0,0,c0z): v_com = vb + w x c0
   V3<T> fD0, tD0;
-  fluid(boxdim(M.I0y, M.I0z, M.I0x, M.m0), boxdim(M.I0x, M.I0z, M.I0y, M.m0), boxdim(M.I0x, M.I0y, M.I0z, M.m0), w,
-        vb + wxc0, &fD0, &tD0);
-  const V3<T> sns = mk<T>(T(0), T(0), T(Const::sense_z));
-  const V3<T> sens_vel = cross(w, cross(w, sns));  // w x (w x s)
+  fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w,
+        mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
+  // u = w x (w x zhat): velocity-product acceleration per unit height on the body z axis
+  const V3<T> u = mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y));
+  const T sz = T(Const::sense_z);
 
   if (!LOAD) {
     // single rigid body: rotate about the COM, then recover the origin acceleration
-    const V3<T> fl = fT + fD0 - F0;
+    const V3<T> ac0 = gt + M.c0z * u;
+    const V3<T> fl = fT + fD0 - M.m0 * ac0;
+    const V3<T> N0 = mk<T>(w.y * w.z * (M.I0z - M.I0y), w.z * w.x * (M.I0x - M.I0z), w.x * w.y * (M.I0y - M.I0x));
     const V3<T> to = tT + tD0 - N0;  // c0 x thrust = 0 (both along z)
-    const V3<T> al = mk<T>(to.x / M.I0x, to.y / M.I0y, to.z / M.I0z);
-    const V3<T> a0 = (T(1) / M.m0) * fl - cross(al, c0);
+    const V3<T> al = mk<T>(to.x * frcp(M.I0x), to.y * frcp(M.I0y), to.z * frcp(M.I0z));
+    const V3<T> a0 = frcp(M.m0) * fl - mk<T>(al.y * M.c0z, -al.x * M.c0z, T(0));
     ex->lin = mul(R, a0); ex->ang = al; ex->thdd1 = ex->thdd2 = T(0);
     *im = *ex;
-    *acc = a0 + gt + cross(al, sns) + sens_vel;
+    *acc = a0 + gt + mk<T>(al.y * sz, -al.x * sz, T(0)) + sz * u;
     return;
   }
 
-  // ---- tether geometry ------------------------------------------------------
+  // ---- tether geometry (float32 trigonometry) -------------------------------------------
   T s1, c1, s2, c2;
   qsincos(s.th1, &s1, &c1);
   qsincos(s.th2, &s2, &c2);
-  const T m1 = T(Const::m1), i1 = T(Const::I1);
-  const V3<T> a = mk<T>(T(0), T(0), T(Const::anchor_z));
+  const T az = T(Const::anchor_z);
   const V3<T> d = mk<T>(-s2, s1 * c2, -c1 * c2);   // unit vector anchor -> load (F0 axes)
   const V3<T> y2 = mk<T>(T(0), c1, s1);            // hinge-2 axis (F0 axes); hinge-1 axis is x
-  const V3<T> rho = M.lc * d;                      // anchor -> tether COM
-  const T dI = M.I2a - M.I2t;
+  const V3<T> e_x = mk<T>(c2, s1 * s2, -c1 * s2);  // x axis of the tether frame F2 = Rx Ry (its z axis is -d)
 
-  // velocities
-  const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
-  const V3<T> w2 = w1 + s.thd2 * y2;
-  // velocity-product accelerations (all generalised accelerations zero, origin accel = g~)
-  const V3<T> wxa = cross(w, a);
-  const V3<T> aa = gt + cross(w, wxa);
-  const V3<T> al1 = mk<T>(T(0), s.thd1 * w.z, -s.thd1 * w.y);   // thd1 * (w x xhat)
-  const V3<T> al2 = al1 + s.thd2 * cross(w1, y2);
-  const V3<T> w2xr = cross(w2, rho);
-  const V3<T> ac2 = aa + cross(al2, rho) + cross(w2, w2xr);
-  // inertial wrenches
-  const V3<T> F1 = m1 * aa;
-  const V3<T> N1 = i1 * al1;
-  const V3<T> F2 = M.m2 * ac2;
-  const T dw = dot(d, w2), da = dot(d, al2);
-  const V3<T> N2 = M.I2t * al2 + (dI * da) * d + (dI * dw) * cross(w2, d);
-
-  // fluid drag on link (frame F1 = Rx(th1)) and tether (frame F2 = Rx(th1) Ry(th2))
-  const V3<T> va = vb + wxa;       // anchor velocity
-  const V3<T> vc2 = va + w2xr;     // tether COM velocity
+  // ---- fluid drag on link (frame F1 = Rx(th1)) and tether (frame F2), float32 ------------
   V3<T> fD1, tD1, fD2, tD2;
   {
-    const T b1 = boxdim(i1, i1, i1, m1);
+    const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
+    const V3<T> w2 = w1 + s.thd2 * y2;
+    const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);  // anchor velocity
+    const V3<T> vc2 = va + M.lc * cross(w2, d);                      // tether COM velocity
+    const T k1 = T(LinkFluid::klin), k2 = T(LinkFluid::kang), k3 = T(LinkFluid::ql), k4 = T(LinkFluid::qa);
     // F0 -> F1 components: Rx^T v = (x, c1 y + s1 z, -s1 y + c1 z)
-    V3<T> wl = mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z);
-    V3<T> vl = mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z);
     V3<T> fl, tl;
-    fluid(b1, b1, b1, wl, vl, &fl, &tl);
+    fluid(k1, k2, k3, k3, k3, k4, k4, k4, mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z),
+          mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z), &fl, &tl);
     fD1 = mk<T>(fl.x, c1 * fl.y - s1 * fl.z, s1 * fl.y + c1 * fl.z);
     tD1 = mk<T>(tl.x, c1 * tl.y - s1 * tl.z, s1 * tl.y + c1 * tl.z);
-  }
-  {
-    // E = Rx Ry: columns ex = (c2, s1 s2, -c1 s2), ey = (0, c1, s1) = y2, ez = (s2, -s1 c2, c1 c2) = -d
-    const V3<T> e_x = mk<T>(c2, s1 * s2, -c1 * s2);
-    const T bt = boxdim(M.I2t, M.I2a, M.I2t, M.m2);   // x and y dims
-    const T ba = boxdim(M.I2t, M.I2t, M.I2a, M.m2);   // along the tether
-    V3<T> wl = mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2));
-    V3<T> vl = mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2));
-    V3<T> fl, tl;
-    fluid(bt, bt, ba, wl, vl, &fl, &tl);
+    fluid(M.klin2, M.kang2, M.qlt2, M.qlt2, M.qla2, M.qat2, M.qat2, M.qaa2,
+          mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2)), mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2)), &fl, &tl);
     fD2 = fl.x * e_x + fl.y * y2 - fl.z * d;
     tD2 = tl.x * e_x + tl.y * y2 - tl.z * d;
   }
 
-  // ---- generalised forces (applied minus velocity-product inertial) -----------
-  const V3<T> r2 = a + rho;
-  const V3<T> fl = fT + fD0 + fD1 + fD2 - (F0 + F1 + F2);
-  const V3<T> W2 = tD2 - N2 + cross(rho, fD2 - F2);   // wrench on the tether about the anchor
-  const V3<T> fw = tT + tD0 - N0 + cross(c0, fD0 - F0) + (tD1 - N1) + cross(a, (fD1 - F1) + (fD2 - F2)) + W2;
-  const T bd = T(Const::damping);
-  const T ft1 = (tD1.x - N1.x) + W2.x - bd * s.thd1;
-  const T ft2 = dot(y2, W2) - bd * s.thd2;
+  // ---- velocity-product terms and generalised forces, HP ---------------------------------
+  const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc;
+  const HP c0z = M.c0z, azh = Const::anchor_z;
+  const HP dI = HP(M.I2a) - It;
+  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt), dh = cvt<HP>(d), y2h = cvt<HP>(y2);
+  const V3<HP> uh = mk<HP>(wh.x * wh.z, wh.y * wh.z, -(wh.x * wh.x + wh.y * wh.y));
+  const HP thd1 = s.thd1, thd2 = s.thd2;
+  const V3<HP> rho = lc * dh;                                         // anchor -> tether COM
+  const V3<HP> w1 = mk<HP>(wh.x + thd1, wh.y, wh.z);
+  const V3<HP> w2 = w1 + thd2 * y2h;
+  // accelerations with all generalised accelerations zero and origin acceleration g~
+  const V3<HP> aa = gth + azh * uh;                                   // anchor
+  const V3<HP> al1 = mk<HP>(HP(0), thd1 * wh.z, -thd1 * wh.y);        // thd1 * (w x xhat)
+  const V3<HP> al2 = al1 + thd2 * cross(w1, y2h);
+  const V3<HP> ac2 = aa + cross(al2, rho) + dot(w2, rho) * w2 - dot(w2, w2) * rho;
+  // inertial wrenches
+  const V3<HP> F0 = m0 * (gth + c0z * uh);
+  const V3<HP> N0 = mk<HP>(wh.y * wh.z * (HP(M.I0z) - HP(M.I0y)), wh.z * wh.x * (HP(M.I0x) - HP(M.I0z)),
+                           wh.x * wh.y * (HP(M.I0y) - HP(M.I0x)));
+  const V3<HP> F1 = m1 * aa;
+  const V3<HP> N1 = i1 * al1;
+  const V3<HP> F2 = m2 * ac2;
+  const V3<HP> N2 = It * al2 + (dI * dot(dh, al2)) * dh + (dI * dot(dh, w2)) * cross(w2, dh);
+  // applied minus inertial
+  const V3<HP> G0 = cvt<HP>(fD0) - F0, G1 = cvt<HP>(fD1) - F1, G2 = cvt<HP>(fD2) - F2;
+  const V3<HP> fl = cvt<HP>(fT) + G0 + G1 + G2;
+  const V3<HP> W2 = cvt<HP>(tD2) - N2 + cross(rho, G2);                // wrench on the tether about the anchor
+  const V3<HP> T1 = cvt<HP>(tD1) - N1;
+  const V3<HP> G12 = G1 + G2;
+  const V3<HP> fw = cvt<HP>(tT) + cvt<HP>(tD0) - N0 + mk<HP>(-c0z * G0.y, c0z * G0.x, HP(0)) + T1 +
+                    mk<HP>(-azh * G12.y, azh * G12.x, HP(0)) + W2;
+  const HP bd = Const::damping;
+  const HP ft1 = T1.x + W2.x - bd * thd1;
+  const HP ft2 = dot(y2h, W2) - bd * thd2;
 
-  // ---- mass matrix, reduced about the system COM -------------------------------
-  const T mt = M.m0 + m1 + M.m2, imt = T(1) / mt;
-  const V3<T> S = M.m0 * c0 + m1 * a + M.m2 * r2;
-  const V3<T> rc = imt * S;
-  const V3<T> p1 = M.lc * mk<T>(T(0), c1 * c2, s1 * c2);        // xhat x rho
-  const V3<T> p2 = M.lc * mk<T>(-c2, -s1 * s2, c1 * s2);        // y2 x rho
-  // inertia about the origin, then shifted to the COM (symmetric: xx,yy,zz,xy,xz,yz)
-  const T c0n = M.c0z * M.c0z, an = T(Const::anchor_z * Const::anchor_z), r2n = dot(r2, r2), rcn = dot(rc, rc);
-  const T diag = M.m0 * c0n + i1 + m1 * an + M.I2t + M.m2 * r2n - mt * rcn;
-  T Jxx = M.I0x + diag + dI * d.x * d.x - M.m2 * r2.x * r2.x + mt * rc.x * rc.x;
-  T Jyy = M.I0y + diag + dI * d.y * d.y - M.m2 * r2.y * r2.y + mt * rc.y * rc.y;
-  T Jzz = M.I0z + diag - M.m0 * c0n - m1 * an + dI * d.z * d.z - M.m2 * r2.z * r2.z + mt * rc.z * rc.z;
-  T Jxy = dI * d.x * d.y - M.m2 * r2.x * r2.y + mt * rc.x * rc.y;
-  T Jxz = dI * d.x * d.z - M.m2 * r2.x * r2.z + mt * rc.x * rc.z;
-  T Jyz = dI * d.y * d.z - M.m2 * r2.y * r2.z + mt * rc.y * rc.z;
-  const V3<T> rr = r2 - rc;
-  const V3<T> B1 = mk<T>(i1 + M.I2t, T(0), T(0)) + (dI * d.x) * d + M.m2 * cross(rr, p1);
-  const V3<T> B2 = M.I2t * y2 + M.m2 * cross(rr, p2);
-  const T mu = M.m2 * (mt - M.m2) * imt;
-  const T lc2 = M.lc * M.lc;
-  const T D1 = i1 + M.I2t + dI * s2 * s2 + mu * lc2 * c2 * c2;
-  const T D2 = M.I2t + mu * lc2;
-  const V3<T> fwr = fw - cross(rc, fl);
-  const T k = M.m2 * imt;
-  const T g1 = ft1 - k * dot(p1, fl);
-  const T g2 = ft2 - k * dot(p2, fl);
+  // ---- mass matrix about the system COM: sums of non-negative terms ------------------------
+  const HP mt = m0 + m1 + m2, imt = frcp(mt);
+  const V3<HP> r2 = mk<HP>(rho.x, rho.y, rho.z + azh);
+  const V3<HP> S = mk<HP>(m2 * r2.x, m2 * r2.y, m0 * c0z + m1 * azh + m2 * r2.z);
+  const V3<HP> rc = imt * S;
+  const HP c1h = c1, s1h = s1, c2h = c2, s2h = s2;
+  const V3<HP> p1 = lc * mk<HP>(HP(0), c1h * c2h, s1h * c2h);          // xhat x rho
+  const V3<HP> p2 = lc * mk<HP>(-c2h, -s1h * s2h, c1h * s2h);          // y2 x rho
+  const V3<HP> q2 = r2 - rc;
+  const HP qx = -rc.x, qy = -rc.y, q0z = c0z - rc.z, q1z = azh - rc.z; // core and link COM offsets from the COM
+  const HP m01 = m0 + m1, base = i1 + It;
+  const HP zz01 = m0 * q0z * q0z + m1 * q1z * q1z, z01 = m0 * q0z + m1 * q1z;
+  const HP Jxx = HP(M.I0x) + base + dI * dh.x * dh.x + m01 * qy * qy + zz01 + m2 * (q2.y * q2.y + q2.z * q2.z);
+  const HP Jyy = HP(M.I0y) + base + dI * dh.y * dh.y + m01 * qx * qx + zz01 + m2 * (q2.x * q2.x + q2.z * q2.z);
+  const HP Jzz = HP(M.I0z) + base + dI * dh.z * dh.z + m01 * (qx * qx + qy * qy) + m2 * (q2.x * q2.x + q2.y * q2.y);
+  const HP Jxy = dI * dh.x * dh.y - m01 * qx * qy - m2 * q2.x * q2.y;
+  const HP Jxz = dI * dh.x * dh.z - qx * z01 - m2 * q2.x * q2.z;
+  const HP Jyz = dI * dh.y * dh.z - qy * z01 - m2 * q2.y * q2.z;
+  const V3<HP> B1 = mk<HP>(base, HP(0), HP(0)) + (dI * dh.x) * dh + m2 * cross(q2, p1);
+  const V3<HP> B2 = It * y2h + m2 * cross(q2, p2);
+  const HP mu = m2 * (mt - m2) * imt;
+  const HP lc2 = lc * lc;
+  const HP D1 = base + dI * s2h * s2h + mu * lc2 * c2h * c2h;
+  const HP D2 = It + mu * lc2;
+  const V3<HP> fwr = fw - cross(rc, fl);
+  const HP k = m2 * imt;
+  const HP g1 = ft1 - k * dot(p1, fl);
+  const HP g2 = ft2 - k * dot(p2, fl);
 
-  // ---- LDL^T of the 3x3 block, three right-hand sides ---------------------------
-  const T d0 = T(1) / Jxx;
-  const T l10 = Jxy * d0, l20 = Jxz * d0;
-  const T e1 = Jyy - l10 * Jxy;
-  const T d1 = T(1) / e1;
-  const T t21 = Jyz - l20 * Jxy;
-  const T l21 = t21 * d1;
-  const T e2 = Jzz - l20 * Jxz - l21 * t21;
-  const T d2 = T(1) / e2;
+  // ---- LDL^T of the 3x3 block, three right-hand sides ----------------------------------------
+  const HP d0 = frcp(Jxx);
+  const HP l10 = Jxy * d0, l20 = Jxz * d0;
+  const HP d1 = frcp(Jyy - l10 * Jxy);
+  const HP t21 = Jyz - l20 * Jxy;
+  const HP l21 = t21 * d1;
+  const HP d2 = frcp(Jzz - l20 * Jxz - l21 * t21);
 #define QD_SOLVE3(b, o)                                       \
   {                                                           \
-    T y0 = (b).x, y1 = (b).y - l10 * y0;                      \
-    T y2_ = (b).z - l20 * y0 - l21 * y1;                      \
-    T z2 = y2_ * d2;                                          \
-    T z1 = y1 * d1 - l21 * z2;                                \
-    T z0 = y0 * d0 - l10 * z1 - l20 * z2;                     \
-    (o) = mk<T>(z0, z1, z2);                                  \
+    const HP y0 = (b).x, y1 = (b).y - l10 * y0;               \
+    const HP y2_ = (b).z - l20 * y0 - l21 * y1;               \
+    const HP z2 = y2_ * d2;                                   \
+    const HP z1 = y1 * d1 - l21 * z2;                         \
+    const HP z0 = y0 * d0 - l10 * z1 - l20 * z2;              \
+    (o) = mk<HP>(z0, z1, z2);                                 \
   }
-  V3<T> Xf, X1, X2;
+  V3<HP> Xf, X1, X2;
   QD_SOLVE3(fwr, Xf);
   QD_SOLVE3(B1, X1);
   QD_SOLVE3(B2, X2);
 #undef QD_SOLVE3
   // 2x2 Schur complement on the hinges
-  const T s11 = D1 - dot(B1, X1), s12 = -dot(B1, X2), s22 = D2 - dot(B2, X2);
-  const T q1 = g1 - dot(B1, Xf), q2 = g2 - dot(B2, Xf);
-  const T hb = h * bd;
-#define QD_FINISH(S11, S22, out)                                                       \
-  {                                                                                    \
-    const T idet = T(1) / ((S11) * (S22) - s12 * s12);                                 \
-    const T t1 = ((S22) * q1 - s12 * q2) * idet, t2 = ((S11) * q2 - s12 * q1) * idet;  \
-    const V3<T> al = Xf - t1 * X1 - t2 * X2;                                           \
-    const V3<T> a0 = imt * (fl - cross(al, S) - (M.m2 * t1) * p1 - (M.m2 * t2) * p2);  \
-    (out)->ang = al; (out)->thdd1 = t1; (out)->thdd2 = t2;                             \
-    (out)->lin = a0; /* body axes for now */                                           \
+  const HP s11 = D1 - dot(B1, X1), s12 = -dot(B1, X2), s22 = D2 - dot(B2, X2);
+  const HP q1 = g1 - dot(B1, Xf), q2s = g2 - dot(B2, Xf);
+  const HP hb = HP(h) * bd;
+  V3<HP> a0ex;
+#define QD_FINISH(S11, S22, out, A0)                                                     \
+  {                                                                                      \
+    const HP idet = frcp((S11) * (S22) - s12 * s12);                                     \
+    const HP t1 = ((S22) * q1 - s12 * q2s) * idet, t2 = ((S11) * q2s - s12 * q1) * idet; \
+    const V3<HP> al = Xf - t1 * X1 - t2 * X2;                                            \
+    A0 = imt * (fl - cross(al, S) - (m2 * t1) * p1 - (m2 * t2) * p2);                    \
+    (out)->ang = cvt<T>(al); (out)->thdd1 = T(t1); (out)->thdd2 = T(t2);                 \
   }
-  QD_FINISH(s11, s22, ex);
-  QD_FINISH(s11 + hb, s22 + hb, im);
+  V3<HP> a0im;
+  QD_FINISH(s11, s22, ex, a0ex);
+  QD_FINISH(s11 + hb, s22 + hb, im, a0im);
 #undef QD_FINISH
-  *acc = ex->lin + gt + cross(ex->ang, sns) + sens_vel;
-  ex->lin = mul(R, ex->lin);
-  im->lin = mul(R, im->lin);
+  const V3<T> a0e = cvt<T>(a0ex);
+  *acc = a0e + gt + mk<T>(ex->ang.y * sz, -ex->ang.x * sz, T(0)) + sz * u;
+  ex->lin = mul(R, a0e);
+  im->lin = mul(R, cvt<T>(a0im));
 }
 
 // one physics substep (mj_step with nstep = 1): forward, then Euler advance.
@@ -268,19 +272,19 @@ QD_HD V3<T> substep(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h)
   }
   // quaternion exponential map with the body-frame rate, then renormalise
   {
-    T qn = T(1) / qsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+    T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
     const T w = s.qw * qn, x = s.qx * qn, y = s.qy * qn, z = s.qz * qn;
-    const T wn = qsqrt(s.wx * s.wx + s.wy * s.wy + s.wz * s.wz);
+    const T w2 = s.wx * s.wx + s.wy * s.wy + s.wz * s.wz;
     T ax = T(1), ay = T(0), az = T(0), ang = T(0);
-    if (wn >= T(1e-15)) { const T iw = T(1) / wn; ax = s.wx * iw; ay = s.wy * iw; az = s.wz * iw; ang = h * wn; }
+    if (w2 >= T(1e-30)) { const T iw = frsq(w2); ax = s.wx * iw; ay = s.wy * iw; az = s.wz * iw; ang = h * (w2 * iw); }
     T sh, ch;
     qsincos(T(0.5) * ang, &sh, &ch);
     const T rx = ax * sh, ry = ay * sh, rz = az * sh;
-    T nw = w * ch - x * rx - y * ry - z * rz;
-    T nx = w * rx + x * ch + y * rz - z * ry;
-    T ny = w * ry - x * rz + y * ch + z * rx;
-    T nz = w * rz + x * ry - y * rx + z * ch;
-    qn = T(1) / qsqrt(nw * nw + nx * nx + ny * ny + nz * nz);
+    const T nw = w * ch - x * rx - y * ry - z * rz;
+    const T nx = w * rx + x * ch + y * rz - z * ry;
+    const T ny = w * ry - x * rz + y * ch + z * rx;
+    const T nz = w * rz + x * ry - y * rx + z * ch;
+    qn = frsq(nw * nw + nx * nx + ny * ny + nz * nz);
     s.qw = nw * qn; s.qx = nx * qn; s.qy = ny * qn; s.qz = nz * qn;
   }
   return acc;

@@ -6,8 +6,8 @@
 // consecutive memory per instruction (the widest coalesced access on CDNA4), followed by
 // 6 planes of double[npad] holding the raw float64 model parameters:
 //   POS  (px,py,pz,th1)   QUAT (qw,qx,qy,qz)   VEL (vx,vy,vz,th2)   ANG (wx,wy,wz,thd1)
-//   ACT  (a0..a3)         AUX  (thd2, num_steps:i32, episode:u32, -)
-//   ACC  (accelerometer xyz, -)                 M0..M3 derived model constants (qd_model.h)
+//   ACT  (a0..a3)         AUX  (thd2, num_steps:i32, episode:u32, flags:u32)
+//   ACC  (accelerometer xyz, -)                 M0..M6 derived model constants (qd_model.h)
 //   P0   (mass, arm_len, motor_force, motor_tau) P1 (pendulum_len, weight_mass, -, -)
 //   REF  (x,y,z,yaw) per-env reference (only read when per_env_reference is set)
 // Observations are produced row-major [N,D] (what the policy network consumes); a
@@ -30,7 +30,8 @@
 namespace qd {
 
 enum Group {
-  G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_P0, G_P1, G_REF, NUM_GROUPS
+  G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_M4, G_M5, G_M6, G_P0, G_P1, G_REF,
+  NUM_GROUPS
 };
 constexpr int RAW_PLANES = 6;
 constexpr int PAD = 256;
@@ -45,6 +46,7 @@ struct KArgs {
   int frame_skip, ctrl_map, obs_kind, reward_kind, term_kind;
   float max_distance;
   int max_steps, auto_reset, D;
+  int obs_needs_acc;  // the observation variant reads the accelerometer entries of the state vector
   unsigned long long seed;
   SampleCfg sc;
 };
@@ -57,8 +59,9 @@ struct EnvRegs {  // everything one lane keeps in registers for one env
   float ref[4];
   int num_steps;
   uint32_t episode;
-  float aux_w;
+  uint32_t flags;  // FLAG_ACC_STALE: the stored accelerometer value predates an in-kernel reset
 };
+constexpr uint32_t FLAG_ACC_STALE = 1u;
 
 template <bool LOAD>
 __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
@@ -66,20 +69,27 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   const int np = a.npad;
   const float4 pos = g[G_POS * np + i], qt = g[G_QUAT * np + i], vel = g[G_VEL * np + i], ang = g[G_ANG * np + i];
   const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i], acc = g[G_ACC * np + i];
-  const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i];
+  const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i], m3 = g[G_M3 * np + i];
+  const float4 m4 = g[G_M4 * np + i];
   const float4 p0 = g[G_P0 * np + i], p1 = g[G_P1 * np + i];
   e.s.px = pos.x; e.s.py = pos.y; e.s.pz = pos.z; e.s.th1 = pos.w;
   e.s.qw = qt.x; e.s.qx = qt.y; e.s.qy = qt.z; e.s.qz = qt.w;
   e.s.vx = vel.x; e.s.vy = vel.y; e.s.vz = vel.z; e.s.th2 = vel.w;
   e.s.wx = ang.x; e.s.wy = ang.y; e.s.wz = ang.z; e.s.thd1 = ang.w;
   e.s.a0 = act.x; e.s.a1 = act.y; e.s.a2 = act.z; e.s.a3 = act.w;
-  e.s.thd2 = aux.x; e.num_steps = __float_as_int(aux.y); e.episode = __float_as_uint(aux.z); e.aux_w = aux.w;
+  e.s.thd2 = aux.x; e.num_steps = __float_as_int(aux.y); e.episode = __float_as_uint(aux.z); e.flags = __float_as_uint(aux.w);
   e.acc = mk<float>(acc.x, acc.y, acc.z);
   e.M.m0 = m0.x; e.M.c0z = m0.y; e.M.I0x = m0.z; e.M.I0y = m0.w;
   e.M.I0z = m1.x; e.M.rot = m1.y; e.M.gearF = m1.z; e.M.gearT = m1.w;
-  e.M.inv_tau = m2.x; e.M.m2 = m2.y; e.M.lc = m2.z; e.M.I2t = m2.w;
-  e.M.I2a = 0.f; e.M.pad0 = e.M.pad1 = e.M.pad2 = 0.f;
-  if (LOAD) e.M.I2a = g[G_M3 * np + i].x;
+  e.M.inv_tau = m2.x; e.M.klin0 = m2.y; e.M.kang0 = m2.z; e.M.qlx0 = m2.w;
+  e.M.qly0 = m3.x; e.M.qlz0 = m3.y; e.M.qax0 = m3.z; e.M.qay0 = m3.w;
+  e.M.qaz0 = m4.x; e.M.m2 = m4.y; e.M.lc = m4.z; e.M.I2t = m4.w;
+  e.M.I2a = e.M.klin2 = e.M.kang2 = e.M.qlt2 = e.M.qla2 = e.M.qat2 = e.M.qaa2 = e.M.pad = 0.f;
+  if (LOAD) {
+    const float4 m5 = g[G_M5 * np + i], m6 = g[G_M6 * np + i];
+    e.M.I2a = m5.x; e.M.klin2 = m5.y; e.M.kang2 = m5.z; e.M.qlt2 = m5.w;
+    e.M.qla2 = m6.x; e.M.qat2 = m6.y; e.M.qaa2 = m6.z;
+  }
   e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
   if (a.per_env_ref) {
     const float4 r = g[G_REF * np + i];
@@ -97,7 +107,7 @@ __device__ __forceinline__ void store_env(const KArgs& a, int i, const EnvRegs& 
   g[G_VEL * np + i] = make_float4(e.s.vx, e.s.vy, e.s.vz, e.s.th2);
   g[G_ANG * np + i] = make_float4(e.s.wx, e.s.wy, e.s.wz, e.s.thd1);
   g[G_ACT * np + i] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
-  g[G_AUX * np + i] = make_float4(e.s.thd2, __int_as_float(e.num_steps), __uint_as_float(e.episode), e.aux_w);
+  g[G_AUX * np + i] = make_float4(e.s.thd2, __int_as_float(e.num_steps), __uint_as_float(e.episode), __uint_as_float(e.flags));
   g[G_ACC * np + i] = make_float4(e.acc.x, e.acc.y, e.acc.z, 0.f);
 }
 
@@ -106,11 +116,14 @@ template <bool LOAD>
 __device__ __forceinline__ void refresh_sensor(const KArgs& a, EnvRegs& e) {
   Accel<float> ex, im;
   forward<float, LOAD>(e.M, e.s, a.h, &ex, &im, &e.acc);
+  e.flags &= ~FLAG_ACC_STALE;
 }
 
-// sample_state for this lane's env, episode counter advanced
+// sample_state for this lane's env, episode counter advanced.  eager_sensor: run mj_forward's sensor
+// part now (reset kernels); otherwise only mark the stored reading stale -- it is recomputed by the
+// next physics step anyway, and by the state/observation getters if they run before that step.
 template <bool LOAD>
-__device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e) {
+__device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e, bool eager_sensor) {
   if (a.sc.random_start == QD_START_SIMPLE) {
     sample_simple(a.sc, a.seed, (uint32_t)i, (uint32_t)a.n, e.episode, e.s);
   } else {
@@ -120,7 +133,8 @@ __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e) {
   }
   e.episode += 1u;
   e.num_steps = 0;
-  refresh_sensor<LOAD>(a, e);
+  if (eager_sensor) refresh_sensor<LOAD>(a, e);
+  else e.flags |= FLAG_ACC_STALE;
 }
 
 // ---- observation rows ---------------------------------------------------------------
@@ -130,16 +144,17 @@ __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e) {
 constexpr int OBS_LDS_FLOATS = 64 * QD_MAX_OBS;
 
 template <int NS, int KIND>
-__device__ __forceinline__ void obs_to_lds(const float* sv, const float ref[4], float* row) {
+__device__ __forceinline__ void obs_to_lds(const float* sv, const float ref[4], float* row, const M3<float>* Rq) {
   float o[QD_MAX_OBS];
-  const int n = observe<float, NS, KIND>(sv, ref, o);
+  const int n = observe<float, NS, KIND>(sv, ref, o, Rq);
 #pragma unroll
   for (int k = 0; k < QD_MAX_OBS; k++)
     if (k < n) row[k] = o[k];
 }
 
 template <bool LOAD>
-__device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, const float* sv, float* row) {
+__device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, const float* sv, const M3<float>* Rq,
+                                              float* row) {
   constexpr int NS = LOAD ? 33 : 29;
   if (a.obs_kind == OBS_SIMPLE) {
     float o[6];
@@ -148,17 +163,38 @@ __device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, 
     for (int k = 0; k < 6; k++) row[k] = o[k];
     return;
   }
-#define QD_CALL(K) obs_to_lds<NS, K>(sv, e.ref, row)
+#define QD_CALL(K) obs_to_lds<NS, K>(sv, e.ref, row, Rq)
   QD_OBS_DISPATCH(a.obs_kind, QD_CALL)
 #undef QD_CALL
 }
 
-// copy the wave's staged rows (64 x D floats, contiguous in LDS and in global memory)
+// copy the wave's staged rows (rows x D floats, contiguous in LDS and in global memory; both 16-byte
+// aligned because a wave starts at a multiple of 64 rows): 16 bytes per lane per instruction
 __device__ __forceinline__ void flush_obs(const float* tile, float* dst, int rows, int D) {
   const int lane = threadIdx.x & 63;
-  const int total = rows * D;
-  for (int j = lane; j < total; j += 64) dst[j] = tile[j];
+  const int total = rows * D, n4 = total >> 2;
+  const float4* t4 = reinterpret_cast<const float4*>(tile);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+#pragma unroll 3
+  for (int j = lane; j < n4; j += 64) d4[j] = t4[j];
+  for (int j = (n4 << 2) + lane; j < total; j += 64) dst[j] = tile[j];
 }
+
+#ifdef QD_STAMPS
+// diagnostic build only: per-wave cycle stamps of the step kernel's phases (cdna_hip_programming.md, In-kernel stamps)
+__device__ unsigned long long qd_stamps[64 * 8];
+__device__ unsigned long long qd_rstamps[64 * 2];
+#define QD_STAMP(k)                                                                                   \
+  do {                                                                                                \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    unsigned long long t_;                                                                            \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_stamps[blockIdx.x * 8 + (k)] = t_;           \
+  } while (0)
+#else
+#define QD_STAMP(k)
+#endif
 
 // ---- one full env step for the lane's env (everything after the state is in registers) ----
 template <bool LOAD>
@@ -169,30 +205,33 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   if (a.ctrl_map == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
   for (int k = 0; k < a.frame_skip; k++) e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  QD_STAMP(2);
+  e.flags &= ~FLAG_ACC_STALE;
   e.num_steps += 1;
   float sv[33];
   const float act4[4] = {action.x, action.y, action.z, action.w};
+  M3<float> Rq;
   bool tr;
   float r;
   if (a.term_kind == QD_TERM_SIMPLE) {
     // SimpleDrone.step: terminated = |pos - ref| > 0.5, reward = 0.1 - |pos - ref| (SimpleDrone.py:57-60)
     const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
-    const float d = sqrtf(dx * dx + dy * dy + dz * dz);
+    const float d = qsqrt(dx * dx + dy * dy + dz * dz);
     tr = d > 0.5f;
     r = 0.1f - d;
-    sv[0] = e.s.px; sv[1] = e.s.py; sv[2] = e.s.pz;
   } else {
-    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
     tr = truncated<float>(sv, e.ref, e.num_steps, a.max_distance, a.max_steps);
-    r = reward<float>(a.reward_kind, sv, act4, e.num_steps, e.ref, a.max_distance);
+    r = reward<float>(a.reward_kind, sv, act4, e.num_steps, e.ref, a.max_distance, &Rq);
   }
   if (a.auto_reset && tr) {
-    resample<LOAD>(a, i, e);
-    if (a.term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
+    resample<LOAD>(a, i, e, a.obs_needs_acc != 0);
+    if (a.term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
   *rew = r;
   *trunc = tr ? 1 : 0;
-  write_obs_row<LOAD>(a, e, sv, obs_row);
+  QD_STAMP(3);
+  write_obs_row<LOAD>(a, e, sv, &Rq, obs_row);
   (void)NS;
 }
 
@@ -204,23 +243,39 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* wtile = tile + wave * OBS_LDS_FLOATS;
   const int wave_base = i - lane;  // first env of this wavefront
+#ifdef QD_STAMPS
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_rstamps[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
+#endif
+  QD_STAMP(0);
   if (i < a.n) {
     EnvRegs e;
     load_env<LOAD>(a, i, e);
     const float4 action = reinterpret_cast<const float4*>(actions)[i];
+#ifdef QD_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    QD_STAMP(1);
+#endif
     float r;
     uint8_t t;
     env_step<LOAD>(a, i, e, action, wtile + lane * a.D, &r, &t);
+    QD_STAMP(4);
     store_env(a, i, e);
     reward[i] = r;
     trunc[i] = t;
   }
   // wave-local staging: the LDS tile is private to the wavefront, so no block barrier is needed
   __builtin_amdgcn_wave_barrier();
+  QD_STAMP(5);
   if (wave_base < a.n) {
     const int rows = min(64, a.n - wave_base);
     flush_obs(wtile, obs + (size_t)wave_base * a.D, rows, a.D);
   }
+  QD_STAMP(6);
+#ifdef QD_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QD_STAMP(7);
+  if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_rstamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
 }
 
 // T steps per launch, state in registers between steps
@@ -266,9 +321,11 @@ __global__ __launch_bounds__(BLOCK) void k_observe(KArgs a, float* __restrict__ 
   if (i < a.n) {
     EnvRegs e;
     load_env<LOAD>(a, i, e);
+    if (e.flags & FLAG_ACC_STALE) refresh_sensor<LOAD>(a, e);
     float sv[33];
-    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
-    write_obs_row<LOAD>(a, e, sv, wtile + lane * a.D);
+    M3<float> Rq;
+    drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
+    write_obs_row<LOAD>(a, e, sv, &Rq, wtile + lane * a.D);
   }
   __builtin_amdgcn_wave_barrier();
   if (wave_base < a.n) flush_obs(wtile, obs + (size_t)wave_base * a.D, min(64, a.n - wave_base), a.D);
@@ -283,7 +340,7 @@ __global__ __launch_bounds__(64) void k_reset(KArgs a, const uint8_t* __restrict
   if (mask && !mask[i]) return;
   EnvRegs e;
   load_env<LOAD>(a, i, e);
-  resample<LOAD>(a, i, e);
+  resample<LOAD>(a, i, e, true);
   store_env(a, i, e);
 }
 
@@ -305,10 +362,10 @@ __global__ __launch_bounds__(64) void k_params(KArgs a, ParamCfg pc, uint32_t re
   const Model<double> M = derive_model(raw, &load);
   float4* g = a.g;
   const int np = a.npad;
-  g[G_M0 * np + i] = make_float4((float)M.m0, (float)M.c0z, (float)M.I0x, (float)M.I0y);
-  g[G_M1 * np + i] = make_float4((float)M.I0z, (float)M.rot, (float)M.gearF, (float)M.gearT);
-  g[G_M2 * np + i] = make_float4((float)M.inv_tau, (float)M.m2, (float)M.lc, (float)M.I2t);
-  g[G_M3 * np + i] = make_float4((float)M.I2a, 0.f, 0.f, 0.f);
+  const double* mp = reinterpret_cast<const double*>(&M);
+#pragma unroll
+  for (int k = 0; k < MODEL_FLOATS / 4; k++)
+    g[(G_M0 + k) * np + i] = make_float4((float)mp[4 * k], (float)mp[4 * k + 1], (float)mp[4 * k + 2], (float)mp[4 * k + 3]);
   g[G_P0 * np + i] = make_float4((float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]);
   g[G_P1 * np + i] = make_float4((float)raw[4], (float)raw[5], 0.f, 0.f);
   if (fresh_data) {  // a new MjData: activations and sensordata start at zero
@@ -339,6 +396,7 @@ __global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
   } else {
     float4 aux = g[G_AUX * np + i];
     aux.x = 0.f;
+    aux.w = __uint_as_float(0u);
     g[G_AUX * np + i] = aux;
   }
 }
@@ -383,6 +441,7 @@ __global__ __launch_bounds__(64) void k_get_state(KArgs a, float* __restrict__ q
   if (i >= a.n) return;
   EnvRegs e;
   load_env<LOAD>(a, i, e);
+  if (sens && (e.flags & FLAG_ACC_STALE)) refresh_sensor<LOAD>(a, e);
   if (qpos) {
     float* qp = qpos + (size_t)i * NQ;
     qp[0] = e.s.px; qp[1] = e.s.py; qp[2] = e.s.pz; qp[3] = e.s.qw; qp[4] = e.s.qx; qp[5] = e.s.qy; qp[6] = e.s.qz;
@@ -405,6 +464,7 @@ __global__ __launch_bounds__(64) void k_drone_states(KArgs a, float* __restrict_
   if (i >= a.n) return;
   EnvRegs e;
   load_env<LOAD>(a, i, e);
+  if (e.flags & FLAG_ACC_STALE) refresh_sensor<LOAD>(a, e);
   float sv[33];
   drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv);
 #pragma unroll
@@ -426,7 +486,7 @@ __global__ __launch_bounds__(64) void k_eval_obs(EvalArgs a, const float* __rest
 #pragma unroll
   for (int k = 0; k < NS; k++) sv[k] = states[(size_t)i * NS + k];
   float* row = obs + (size_t)i * a.D;
-#define QD_CALL(K) obs_to_lds<NS, K>(sv, a.ref, row)
+#define QD_CALL(K) obs_to_lds<NS, K>(sv, a.ref, row, nullptr)
   QD_OBS_DISPATCH(a.kind, QD_CALL)
 #undef QD_CALL
 }
@@ -524,6 +584,13 @@ static int fail(int code, const char* fmt, ...) {
     if (e_ != hipSuccess) return fail(QD_ERR_HIP, "%s: %s", #call, hipGetErrorString(e_));     \
   } while (0)
 #define QD_LAUNCH_CHECK() QD_HIP(hipGetLastError())
+// hipGetLastError() is sticky per thread: drop whatever an unrelated earlier HIP call of the host
+// application left behind before launching, so that the check reports THIS launch only
+#define QD_LAUNCH(...)                 \
+  do {                                 \
+    (void)hipGetLastError();           \
+    hipLaunchKernelGGL(__VA_ARGS__);   \
+  } while (0)
 #define QD_NEED(env) \
   if (!(env)) return fail(QD_ERR_INVALID, "null env handle")
 
@@ -534,6 +601,14 @@ extern "C" {
 
 const char* qd_last_error(void) { return g_err; }
 int qd_version(void) { return QD_VERSION; }
+#ifdef QD_STAMPS
+int qd_debug_read_stamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -4;
+}
+int qd_debug_read_rstamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_rstamps), sizeof(unsigned long long) * 64 * 2) == hipSuccess ? 0 : -4;
+}
+#endif
 
 int qd_state_dim(int model) { return model == QD_MODEL_LOAD ? 33 : 29; }
 
@@ -595,6 +670,13 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.frame_skip = c->frame_skip; k.ctrl_map = c->ctrl_map; k.obs_kind = c->obs_kind; k.reward_kind = c->reward_kind;
   k.term_kind = c->term_kind; k.max_distance = (float)c->max_distance; k.max_steps = c->max_steps;
   k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
+  {
+    const int ok = c->obs_kind;
+    const bool reads_acc_load = ok == QD_OBS_RAW || ok == QD_OBS_FULLSTATE || ok == QD_OBS_FULLSTATE_ZVEC || ok == QD_OBS_PRY_ACC ||
+                                ok == QD_OBS_PRY_ACC_PARAMS || ok == QD_OBS_PRY_ACC_NOPEND;
+    // without the load the wrappers' "pendulum" slices alias the accelerometer entries (state[12:15])
+    k.obs_needs_acc = e->load ? (reads_acc_load ? 1 : 0) : (ok != QD_OBS_SIMPLE ? 1 : 0);
+  }
   SampleCfg& sc = k.sc;
   for (int i = 0; i < 4; i++) sc.start_pos[i] = (float)c->start_pos[i];
   sc.max_pos_offset = (float)c->max_pos_offset;
@@ -619,16 +701,16 @@ int qd_init(qd_env* env, void* stream) {
   QD_NEED(env);
   const KArgs& k = env->ka;
   env->regen = 0;
-  hipLaunchKernelGGL(k_init_state, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, 1);
+  QD_LAUNCH(k_init_state, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, 1);
   QD_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_params, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, env->pc, env->regen, (const double*)nullptr, 1);
+  QD_LAUNCH(k_params, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, env->pc, env->regen, (const double*)nullptr, 1);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
 
 int qd_reset_data(qd_env* env, void* stream) {
   QD_NEED(env);
-  hipLaunchKernelGGL(k_init_state, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, 0);
+  QD_LAUNCH(k_init_state, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, 0);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -644,7 +726,7 @@ int qd_set_reference_per_env(qd_env* env, const float* ref, void* stream) {
   QD_NEED(env);
   if (!env->ka.per_env_ref) return fail(QD_ERR_INVALID, "env was created without per_env_reference");
   if (!ref) return fail(QD_ERR_INVALID, "null reference array");
-  hipLaunchKernelGGL(k_set_ref, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, ref);
+  QD_LAUNCH(k_set_ref, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, ref);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -652,7 +734,7 @@ int qd_set_reference_per_env(qd_env* env, const float* ref, void* stream) {
 int qd_randomize_params(qd_env* env, void* stream) {
   QD_NEED(env);
   env->regen += 1;
-  hipLaunchKernelGGL(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen,
+  QD_LAUNCH(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen,
                      (const double*)nullptr, 1);
   QD_LAUNCH_CHECK();
   return QD_OK;
@@ -661,7 +743,7 @@ int qd_randomize_params(qd_env* env, void* stream) {
 int qd_set_params(qd_env* env, const double* raw, void* stream) {
   QD_NEED(env);
   if (!raw) return fail(QD_ERR_INVALID, "null params");
-  hipLaunchKernelGGL(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen, raw, 0);
+  QD_LAUNCH(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen, raw, 0);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -669,22 +751,22 @@ int qd_set_params(qd_env* env, const double* raw, void* stream) {
 int qd_get_params(qd_env* env, double* raw, void* stream) {
   QD_NEED(env);
   if (!raw) return fail(QD_ERR_INVALID, "null output");
-  hipLaunchKernelGGL(k_get_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, raw);
+  QD_LAUNCH(k_get_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, raw);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
 
 #define QD_BY_MODEL(env, KERNEL, grid, block, stream, ...)                                            \
   do {                                                                                                \
-    if ((env)->load) hipLaunchKernelGGL((KERNEL<true>), grid, block, 0, S(stream), __VA_ARGS__);      \
-    else hipLaunchKernelGGL((KERNEL<false>), grid, block, 0, S(stream), __VA_ARGS__);                 \
+    if ((env)->load) QD_LAUNCH((KERNEL<true>), grid, block, 0, S(stream), __VA_ARGS__);      \
+    else QD_LAUNCH((KERNEL<false>), grid, block, 0, S(stream), __VA_ARGS__);                 \
     QD_LAUNCH_CHECK();                                                                                \
   } while (0)
 
 static int launch_observe(qd_env* env, float* obs, void* stream) {
   const KArgs& k = env->ka;
-  if (env->load) hipLaunchKernelGGL((k_observe<true, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
-  else hipLaunchKernelGGL((k_observe<false, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
+  if (env->load) QD_LAUNCH((k_observe<true, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
+  else QD_LAUNCH((k_observe<false, 64>), dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, obs);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -727,12 +809,12 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   // 256-thread workgroups once there are enough waves to fill the chip several times over
   if (k.n >= 65536) {
     const dim3 grid((k.n + 255) / 256), block(256);
-    if (env->load) hipLaunchKernelGGL((k_step<true, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-    else hipLaunchKernelGGL((k_step<false, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    if (env->load) QD_LAUNCH((k_step<true, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    else QD_LAUNCH((k_step<false, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
   } else {
     const dim3 grid(blocks64(k.n)), block(64);
-    if (env->load) hipLaunchKernelGGL((k_step<true, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-    else hipLaunchKernelGGL((k_step<false, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    if (env->load) QD_LAUNCH((k_step<true, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
+    else QD_LAUNCH((k_step<false, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
   }
   QD_LAUNCH_CHECK();
   return QD_OK;
@@ -745,8 +827,8 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   if (T == 0) return QD_OK;
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   const dim3 grid(blocks64(k.n)), block(64);
-  if (env->load) hipLaunchKernelGGL((k_rollout<true, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
-  else hipLaunchKernelGGL((k_rollout<false, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
+  if (env->load) QD_LAUNCH((k_rollout<true, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
+  else QD_LAUNCH((k_rollout<false, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -783,8 +865,8 @@ int qd_eval_obs(int obs_kind, int ns, const float* states, const double ref_host
   if (!states || !obs) return fail(QD_ERR_INVALID, "null array argument");
   a.kind = obs_kind;
   a.D = obs_dim(obs_kind, ns);
-  if (ns == 33) hipLaunchKernelGGL((k_eval_obs<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
-  else hipLaunchKernelGGL((k_eval_obs<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
+  if (ns == 33) QD_LAUNCH((k_eval_obs<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
+  else QD_LAUNCH((k_eval_obs<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, obs);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -800,8 +882,8 @@ int qd_eval_reward(int reward_kind, int ns, const float* states, const float* ac
   if (!states || !actions || !reward) return fail(QD_ERR_INVALID, "null array argument");
   a.kind = reward_kind;
   a.max_distance = (float)max_distance;
-  if (ns == 33) hipLaunchKernelGGL((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
-  else hipLaunchKernelGGL((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
+  if (ns == 33) QD_LAUNCH((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
+  else QD_LAUNCH((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, actions, num_steps, reward, (uint8_t*)nullptr);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -815,8 +897,8 @@ int qd_eval_truncated(int ns, const float* states, const int32_t* num_steps, con
   if (!states || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   a.max_distance = (float)max_distance;
   a.max_steps = max_steps;
-  if (ns == 33) hipLaunchKernelGGL((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
-  else hipLaunchKernelGGL((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
+  if (ns == 33) QD_LAUNCH((k_eval_reward<33>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
+  else QD_LAUNCH((k_eval_reward<29>), dim3(blocks64(n)), dim3(64), 0, S(stream), a, states, (const float*)nullptr, num_steps, (float*)nullptr, truncated);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -826,7 +908,7 @@ int qd_transform(int which, const float* in, float* out, int n, void* stream) {
   if (n < 0) return fail(QD_ERR_INVALID, "negative row count");
   if (n == 0) return QD_OK;
   if (!in || !out) return fail(QD_ERR_INVALID, "null array argument");
-  hipLaunchKernelGGL(k_transform, dim3(blocks64(n)), dim3(64), 0, S(stream), which, in, out, n);
+  QD_LAUNCH(k_transform, dim3(blocks64(n)), dim3(64), 0, S(stream), which, in, out, n);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }

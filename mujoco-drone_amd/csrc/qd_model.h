@@ -34,13 +34,31 @@ struct Const {
   static constexpr double I1 = 0.4 * 0.01 * 0.02 * 0.02;  // solid sphere
 };
 
-// per-env derived constants (float32 on the device; 13 used, padded to 4 float4)
+// per-env derived constants (float32 in the arena, 7 float4 planes).  The inertia-box
+// fluid coefficients (MuJoCo's mj_inertiaBoxFluidModel) only depend on the parameters, so
+// they are folded here once per regeneration instead of 7 sqrt + 7 divisions per step:
+//   box_i = sqrt(6 (I_j + I_k - I_i) / m),  d = mean(box)
+//   klin = 3 pi d mu, kang = pi d^3 mu, ql_i = rho/2 box_j box_k, qa_i = rho box_i (box_j^4 + box_k^4) / 64
+// so that force_i = -(klin + ql_i |v_i|) v_i and torque_i = -(kang + qa_i |w_i|) w_i.
 template <class T>
 struct Model {
-  T m0, c0z, I0x, I0y;        // group M0
-  T I0z, rot, gearF, gearT;   // group M1
-  T inv_tau, m2, lc, I2t;     // group M2
-  T I2a, pad0, pad1, pad2;    // group M3
+  T m0, c0z, I0x, I0y;           // plane M0: core mass, COM height, inertia about the COM (body axes)
+  T I0z, rot, gearF, gearT;      // plane M1: |x|=|y| of the rotor sites, thrust and yaw-torque gears
+  T inv_tau, klin0, kang0, qlx0; // plane M2: 1/motor_tau, core fluid coefficients
+  T qly0, qlz0, qax0, qay0;      // plane M3
+  T qaz0, m2, lc, I2t;           // plane M4: tether+load mass, COM distance, transverse inertia
+  T I2a, klin2, kang2, qlt2;     // plane M5: axial inertia, tether fluid coefficients (t = x,y; a = z)
+  T qla2, qat2, qaa2, pad;       // plane M6
+};
+constexpr int MODEL_FLOATS = 28;
+
+// link sphere (env_gen.py:68): its inertia box is a cube of side r*sqrt(2.4)
+struct LinkFluid {
+  static constexpr double b = 0.02 * 1.5491933384829668;
+  static constexpr double klin = 3.0 * 3.14159265358979323846 * b * Const::viscosity;
+  static constexpr double kang = 3.14159265358979323846 * b * b * b * Const::viscosity;
+  static constexpr double ql = 0.5 * Const::density * b * b;
+  static constexpr double qa = Const::density * b * (2.0 * b * b * b * b) / 64.0;
 };
 
 // round to 5 significant digits the way "%.5g" + strtod does (env_gen.py:129)
@@ -61,6 +79,21 @@ QD_HD double round5(double x) {
     r = rint(ax / p10[k]) * p10[k];
   }
   return x < 0 ? -r : r;
+}
+
+QD_HD void fluid_coeffs(double Ix, double Iy, double Iz, double mass, double* klin, double* kang, double ql[3], double qa[3]) {
+  const double pi = 3.14159265358979323846;
+  const double bx = sqrt(fmax(1e-15, Iy + Iz - Ix) / mass * 6.0);
+  const double by = sqrt(fmax(1e-15, Ix + Iz - Iy) / mass * 6.0);
+  const double bz = sqrt(fmax(1e-15, Ix + Iy - Iz) / mass * 6.0);
+  const double d = (bx + by + bz) / 3.0;
+  *klin = 3.0 * pi * d * Const::viscosity;
+  *kang = pi * d * d * d * Const::viscosity;
+  ql[0] = 0.5 * Const::density * by * bz; ql[1] = 0.5 * Const::density * bx * bz; ql[2] = 0.5 * Const::density * bx * by;
+  const double bx4 = bx * bx * bx * bx, by4 = by * by * by * by, bz4 = bz * bz * bz * bz;
+  qa[0] = Const::density * bx * (by4 + bz4) / 64.0;
+  qa[1] = Const::density * by * (bx4 + bz4) / 64.0;
+  qa[2] = Const::density * bz * (bx4 + by4) / 64.0;
 }
 
 // raw = (mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass)
@@ -108,8 +141,13 @@ QD_HD Model<double> derive_model(const double raw[6], bool* load_out) {
   M.gearT = round5(F / 100);
   const double t = round5(tau);
   M.inv_tau = 1.0 / (t > 1e-15 ? t : 1e-15);
+  {
+    double ql[3], qa[3], kl, ka;
+    fluid_coeffs(M.I0x, M.I0y, M.I0z, M.m0, &kl, &ka, ql, qa);
+    M.klin0 = kl; M.kang0 = ka; M.qlx0 = ql[0]; M.qly0 = ql[1]; M.qlz0 = ql[2]; M.qax0 = qa[0]; M.qay0 = qa[1]; M.qaz0 = qa[2];
+  }
   const bool load = (pl > 0 && wm > 0);  // env_gen.py:33-35
-  M.m2 = M.lc = M.I2t = M.I2a = 0;
+  M.m2 = M.lc = M.I2t = M.I2a = M.klin2 = M.kang2 = M.qlt2 = M.qla2 = M.qat2 = M.qaa2 = 0;
   if (load) {
     const double mp = round5(0.2 * pl), mw = round5(wm);
     const double rr = round5(0.005), rh = round5(pl / 2), rz = round5(-pl / 2);
@@ -120,8 +158,11 @@ QD_HD Model<double> derive_model(const double raw[6], bool* load_out) {
     M.lc = -c2z;
     M.I2t = mp * (3 * rr * rr + 4 * rh * rh) / 12 + mp * d_r * d_r + mw / 3 * (2 * bs * bs) + mw * d_w * d_w;
     M.I2a = mp * rr * rr / 2 + mw / 3 * (2 * bs * bs);
+    double ql[3], qa[3], kl, ka;
+    fluid_coeffs(M.I2t, M.I2t, M.I2a, M.m2, &kl, &ka, ql, qa);
+    M.klin2 = kl; M.kang2 = ka; M.qlt2 = ql[0]; M.qla2 = ql[2]; M.qat2 = qa[0]; M.qaa2 = qa[2];
   }
-  M.pad0 = M.pad1 = M.pad2 = 0;
+  M.pad = 0;
   *load_out = load;
   return M;
 }

@@ -57,10 +57,12 @@ QD_HD void quat2rpy(T w, T x, T y, T z, T* roll, T* pitch, T* yaw) {
 
 // state vector from the simulator state (BaseDroneEnv.py:365-379)
 template <class T, bool LOAD>
-QD_HD void drone_state(const State<T>& s, V3<T> acc, const T ref[4], const T par[6], T* o /* 33 or 29 */) {
-  T qn = T(1) / qsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+QD_HD void drone_state(const State<T>& s, V3<T> acc, const T ref[4], const T par[6], T* o /* 33 or 29 */,
+                       M3<T>* Rout = nullptr) {
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
   T r, p, y;
   quat2rpy(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn, &r, &p, &y);
+  if (Rout) *Rout = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
   o[0] = s.px; o[1] = s.py; o[2] = s.pz; o[3] = r; o[4] = p; o[5] = y;
   o[6] = s.vx; o[7] = s.vy; o[8] = s.vz; o[9] = s.wx; o[10] = s.wy; o[11] = s.wz;
   if (LOAD) {
@@ -92,8 +94,10 @@ QD_HD M3<T> rpy2mat(T roll, T pitch, T yaw) {
 // be placed in scratch memory); kernels dispatch with QD_OBS_DISPATCH.  `ref` is
 // env.reference (the wrappers use self.reference, not the copy inside the state).
 // Returns the number of values written.
+// `Rq`: optional attitude matrix already computed from the quaternion (fused kernels); without
+// it the matrix is rebuilt from (roll, pitch, yaw) like the reference does.
 template <class T, int NS, int kind>
-QD_HD int observe(const T* s, const T ref[4], T* o) {
+QD_HD int observe(const T* s, const T ref[4], T* o, const M3<T>* Rq = nullptr) {
   constexpr int NP = NS - 27;  // QUIRK C-7: `params = state[27:]` has 6 entries with the load, 2 without
   const T pi = T(3.14159265358979323846);
   if (kind == OBS_RAW) {
@@ -110,7 +114,7 @@ QD_HD int observe(const T* s, const T ref[4], T* o) {
     for (int i = 0; i < 10; i++) o[6 + i] = s[6 + i];
     return 16;
   }
-  const M3<T> R = rpy2mat(roll, pitch, yaw);
+  const M3<T> R = Rq ? *Rq : rpy2mat(roll, pitch, yaw);
   const V3<T> el = mulT(R, eg), vl = mulT(R, mk<T>(s[6], s[7], s[8]));
   int n = 0;
   o[n++] = el.x; o[n++] = el.y; o[n++] = el.z;
@@ -118,12 +122,29 @@ QD_HD int observe(const T* s, const T ref[4], T* o) {
                     kind == OBS_PRY_ACC_PARAMS || kind == OBS_PRY_ACC_NOPEND);
   const bool zv = (kind == OBS_FULLSTATE_ZVEC || kind == OBS_ZVEC);
   if (kind == OBS_RM_PARAMS) {
-    const M3<T> Rm = rpy2mat(roll, pitch, -hd);  // flattened transpose
+    M3<T> Rm;  // DCM([roll, pitch, -hd]); -hd = yaw - ref_yaw (mod 2 pi), so Rm = Rz(-ref_yaw) R
+    if (Rq) {
+      T sy, cy;
+      qsincos(ref[3], &sy, &cy);
+      Rm.m00 = cy * R.m00 + sy * R.m10; Rm.m01 = cy * R.m01 + sy * R.m11; Rm.m02 = cy * R.m02 + sy * R.m12;
+      Rm.m10 = cy * R.m10 - sy * R.m00; Rm.m11 = cy * R.m11 - sy * R.m01; Rm.m12 = cy * R.m12 - sy * R.m02;
+      Rm.m20 = R.m20; Rm.m21 = R.m21; Rm.m22 = R.m22;
+    } else {
+      Rm = rpy2mat(roll, pitch, -hd);
+    }
+    // flattened transpose
     o[n++] = Rm.m00; o[n++] = Rm.m10; o[n++] = Rm.m20; o[n++] = Rm.m01; o[n++] = Rm.m11; o[n++] = Rm.m21;
     o[n++] = Rm.m02; o[n++] = Rm.m12; o[n++] = Rm.m22;
   } else if (zv) {
-    const M3<T> Rz = rpy2mat(roll, pitch, T(0));
-    o[n++] = Rz.m02; o[n++] = Rz.m12; o[n++] = Rz.m22; o[n++] = hd;
+    // third column of DCM([roll, pitch, 0]) = (sp cr, -sr, cp cr); from R: R20 = -sp, R21 = cp sr, R22 = cp cr
+    if (Rq) {
+      const T icp = frsq(qmax(R.m21 * R.m21 + R.m22 * R.m22, T(1e-30)));
+      o[n++] = -R.m20 * R.m22 * icp; o[n++] = -R.m21 * icp; o[n++] = R.m22;
+    } else {
+      const M3<T> Rz = rpy2mat(roll, pitch, T(0));
+      o[n++] = Rz.m02; o[n++] = Rz.m12; o[n++] = Rz.m22;
+    }
+    o[n++] = hd;
   } else {
     o[n++] = pry ? pitch : roll; o[n++] = pry ? roll : pitch; o[n++] = hd;
   }
@@ -153,7 +174,7 @@ QD_HD int observe(const T* s, const T ref[4], T* o) {
 // (w,x,y,z) as if it were (x,y,z,w) and asked for extrinsic 'zyx' angles.
 template <class T>
 QD_HD void simple_obs(const State<T>& s, T* o) {
-  T qn = T(1) / qsqrt(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
   const M3<T> R = quat2mat(s.qz * qn, s.qw * qn, s.qx * qn, s.qy * qn);
   o[0] = s.px; o[1] = s.py; o[2] = s.pz;
   o[3] = qatan2(-R.m01, R.m00);
@@ -163,7 +184,7 @@ QD_HD void simple_obs(const State<T>& s, T* o) {
 
 // ------------------------------------------------------------------ rewards
 template <class T>
-QD_HD T reward(int kind, const T* s, const T a[4], int k, const T ref[4], T max_distance) {
+QD_HD T reward(int kind, const T* s, const T a[4], int k, const T ref[4], T max_distance, const M3<T>* Rq = nullptr) {
   const T pi = T(3.14159265358979323846);
   const V3<T> dv = mk<T>(s[0] - ref[0], s[1] - ref[1], s[2] - ref[2]);
   const T d2 = dot(dv, dv);
@@ -200,7 +221,7 @@ QD_HD T reward(int kind, const T* s, const T a[4], int k, const T ref[4], T max_
     default: break;
   }
   // the remaining rewards need the attitude matrix and the tether geometry
-  const M3<T> Rd = rpy2mat(s[3], s[4], s[5]);
+  const M3<T> Rd = Rq ? *Rq : rpy2mat(s[3], s[4], s[5]);
   T s1, c1, s2, c2;
   qsincos(s[12], &s1, &c1);
   qsincos(s[13], &s2, &c2);

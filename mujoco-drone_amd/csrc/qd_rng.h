@@ -52,11 +52,16 @@ QD_HD void sample_draws(uint64_t seed, uint32_t env, uint32_t episode, float z[1
 #pragma unroll
   for (uint32_t b = 0; b < 5; b++) philox4x32_10(env, episode, b, STREAM_STATE, k0, k1, w + 4 * b);
 #pragma unroll
-  for (int i = 0; i < 8; i++) {  // Box-Muller pairs
+  for (int i = 0; i < 8; i++) {  // Box-Muller pairs: r = sqrt(-2 ln u1), angle = 2 pi u2
     const float u1 = u32_to_unit(w[2 * i]), u2 = u32_to_unit(w[2 * i + 1]);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // v_log_f32 is log2; v_sin_f32 / v_cos_f32 take their argument in revolutions, i.e. u2 itself
+    const float r = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1));
+    const float sn = __builtin_amdgcn_sinf(u2), cs = __builtin_amdgcn_cosf(u2);
+#else
     const float r = sqrtf(-2.0f * logf(u1)), a = 6.28318530717958647692f * u2;
-    float sn, cs;
-    qsincos(a, &sn, &cs);
+    const float sn = sinf(a), cs = cosf(a);
+#endif
     z[2 * i] = r * cs;
     z[2 * i + 1] = r * sn;
   }
@@ -69,7 +74,7 @@ template <bool LOAD>
 QD_HD void sample_state(const SampleCfg& c, const float z[16], const float u[2], State<float>& s) {
   float roll = 0.f, pitch = 0.f, yaw = c.start_pos[3];
   if (c.random_start == 1) {
-    const float inv = 1.0f / sqrtf(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
+    const float inv = frsq(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);
     const float r = c.max_pos_offset * cbrtf(u[0]);
     s.px = c.start_pos[0] + r * (z[0] * inv);
     s.py = c.start_pos[1] + r * (z[1] * inv);

@@ -174,6 +174,7 @@ class BaseDroneEnv(_VectorEnvBase):
         self.num_envs = self.num_drones
         self._host_cache = {}
         self._obs_host = None
+        self._ref_pushed = self._reference
         self.num_steps = np.zeros((self.num_drones,), dtype=np.int64)
         qpos, qvel = self._flat_state()[:2]
         self.init_qpos, self.init_qvel = qpos.copy(), qvel.copy()
@@ -226,6 +227,7 @@ class BaseDroneEnv(_VectorEnvBase):
 
     def _push_reference(self):
         self._dev.set_reference(self._reference)  # also catches in-place edits of the list/array
+        self._ref_pushed = self._reference
 
     @property
     def dt(self):
@@ -373,11 +375,12 @@ class BaseDroneEnv(_VectorEnvBase):
         """actions: float32 CUDA tensor [N,4].  Returns device tensors (obs [N,D] f32, reward [N] f32,
         truncated [N] u8); they alias internal buffers (or `out=(obs, reward, truncated)`) and stay valid
         until the next step.  The regen rule of vector_step is applied."""
-        self._push_reference()
+        if self._reference is not self._ref_pushed:
+            self._push_reference()
         o, r, t = out if out is not None else (None, None, None)
         obs, rew, trunc = self._dev.step(actions, o, r, t)
         self.total_steps += 1
-        self._invalidate()
+        self._host_cache = {}
         self._obs_host = None
         if self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps:
             self.total_steps = 0

@@ -13,6 +13,13 @@ def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else None
 
 
+try:  # raw hipStream_t of torch's current stream without building a Stream object (hot path)
+    _raw_stream = torch._C._cuda_getCurrentRawStream
+except AttributeError:  # pragma: no cover
+    def _raw_stream(index):
+        return torch.cuda.current_stream(index).cuda_stream
+
+
 class DeviceEnv:
     def __init__(self, cfg: L.QdConfig, device="cuda:0"):
         self.lib = L.lib()  # raises if libqd.so is missing: no CPU path
@@ -36,6 +43,8 @@ class DeviceEnv:
         handle = C.c_void_p()
         L.check(self.lib.qd_create(C.byref(cfg), _ptr(self.arena), nbytes, C.byref(handle)))
         self.handle = handle
+        self._qd_step = self.lib.qd_step
+        self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         L.check(self.lib.qd_init(self.handle, self._stream()))
 
     def __del__(self):
@@ -109,16 +118,19 @@ class DeviceEnv:
         return qpos, qvel, act, sens, steps
 
     def step(self, actions, obs=None, reward=None, truncated=None):
-        """actions: float32 device tensor with 4*N values (anything else raises ValueError like the reference)."""
-        if not (isinstance(actions, torch.Tensor) and actions.device == self.device and
-                actions.dtype == torch.float32 and actions.is_contiguous()):
+        """actions: float32 device tensor with 4*N values (anything else raises ValueError like the reference).
+        Hot path: one ctypes call -> one kernel launch on torch's current stream, no allocation, no sync."""
+        if (type(actions) is not torch.Tensor or actions.dtype is not torch.float32 or actions.device != self.device
+                or not actions.is_contiguous()):
             actions = torch.as_tensor(np.asarray(actions, dtype=np.float32) if not isinstance(actions, torch.Tensor)
                                       else actions).to(device=self.device, dtype=torch.float32).contiguous()
         obs = self.obs if obs is None else obs
         reward = self.reward if reward is None else reward
         truncated = self.truncated if truncated is None else truncated
-        L.check(self.lib.qd_step(self.handle, _ptr(actions), actions.numel(), _ptr(obs), _ptr(reward), _ptr(truncated),
-                                 self._stream()))
+        rc = self._qd_step(self.handle, actions.data_ptr(), actions.numel(), obs.data_ptr(), reward.data_ptr(),
+                           truncated.data_ptr(), _raw_stream(self._dev_index))
+        if rc:
+            L.check(rc)
         return obs, reward, truncated
 
     def rollout(self, actions, obs=None, reward=None, truncated=None):
@@ -148,9 +160,12 @@ class DeviceEnv:
     def model_constants(self):
         """per-env derived model constants (qd_model.h), read straight from the arena planes"""
         npad = (self.n + 255) // 256 * 256
-        g = self.arena[:14 * npad * 16].view(torch.float32).view(14, npad, 4)[:, :self.n]
-        names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "m2", "lc", "I2t", "I2a"]
-        flat = torch.cat([g[7], g[8], g[9], g[10]], dim=1)
+        ngroups, first = 17, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
+        g = self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
+        names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "klin0", "kang0", "qlx0",
+                 "qly0", "qlz0", "qax0", "qay0", "qaz0", "m2", "lc", "I2t", "I2a", "klin2", "kang2", "qlt2", "qla2",
+                 "qat2", "qaa2"]
+        flat = torch.cat([g[first + k] for k in range(7)], dim=1)
         return {k: flat[:, i].clone() for i, k in enumerate(names)}
 
 
@@ -214,7 +229,7 @@ def eval_truncated(states, num_steps, ref, max_distance, max_steps, device=None)
 def transform(which, x, in_dim, out_dim, device=None):
     dev = _dev(device)
     arr = np.asarray(x, dtype=np.float32)
-    single = arr.ndim == 1 or (which == L.TF_DCM2QUAT and arr.ndim == 2)
+    single = arr.ndim == 1 or (which == L.TF_DCM2QUAT and arr.shape == (3, 3))
     t = torch.as_tensor(arr.reshape(-1, in_dim)).to(dev).contiguous()
     out = torch.empty((t.shape[0], out_dim), dtype=torch.float32, device=dev)
     L.check(L.lib().qd_transform(which, _ptr(t), _ptr(out), t.shape[0], _stream(dev)))

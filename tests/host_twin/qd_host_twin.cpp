@@ -13,7 +13,7 @@ static void run_step(int load, const double* model16, double* qpos, double* qvel
                      double h, int nstep, double* sensor) {
   Model<T> M;
   T* mp = reinterpret_cast<T*>(&M);
-  for (int i = 0; i < 16; i++) mp[i] = (T)model16[i];
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = (T)model16[i];
   State<T> s;
   s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2];
   s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
@@ -34,11 +34,11 @@ static void run_step(int load, const double* model16, double* qpos, double* qvel
 }
 
 extern "C" {
-int twin_derive(const double raw[6], double out16[16]) {
+int twin_derive(const double raw[6], double out16[MODEL_FLOATS]) {
   bool load;
   Model<double> M = derive_model(raw, &load);
   const double* mp = reinterpret_cast<const double*>(&M);
-  for (int i = 0; i < 16; i++) out16[i] = mp[i];
+  for (int i = 0; i < MODEL_FLOATS; i++) out16[i] = mp[i];
   return load ? 1 : 0;
 }
 double twin_round5(double x) { return round5(x); }

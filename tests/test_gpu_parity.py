@@ -142,6 +142,20 @@ def test_reward_objects_callable_like_reference(qd, golden):
     assert abs(r - golden["rew_distance_energy_reward"][i]) < 1e-4
 
 
+def fluid_coeffs(Ix, Iy, Iz, mass, tag, rho=1.2, mu=2e-5):
+    """MuJoCo's inertia-box fluid coefficients, written out independently of csrc/qd_model.h"""
+    b = [np.sqrt(max(1e-15, Iy + Iz - Ix) / mass * 6), np.sqrt(max(1e-15, Ix + Iz - Iy) / mass * 6),
+         np.sqrt(max(1e-15, Ix + Iy - Iz) / mass * 6)]
+    d = sum(b) / 3
+    ql = [0.5 * rho * b[1] * b[2], 0.5 * rho * b[0] * b[2], 0.5 * rho * b[0] * b[1]]
+    qa = [rho * b[0] * (b[1] ** 4 + b[2] ** 4) / 64, rho * b[1] * (b[0] ** 4 + b[2] ** 4) / 64,
+          rho * b[2] * (b[0] ** 4 + b[1] ** 4) / 64]
+    if tag == "0":
+        return dict(klin0=3 * np.pi * d * mu, kang0=np.pi * d ** 3 * mu, qlx0=ql[0], qly0=ql[1], qlz0=ql[2], qax0=qa[0],
+                    qay0=qa[1], qaz0=qa[2])
+    return dict(klin2=3 * np.pi * d * mu, kang2=np.pi * d ** 3 * mu, qlt2=ql[0], qla2=ql[2], qat2=qa[0], qaa2=qa[2])
+
+
 # ------------------------------------------------------------------ model constants
 @pytest.mark.parametrize("load", [True, False])
 def test_model_constants_vs_oracle(qd, orc, load):
@@ -157,6 +171,9 @@ def test_model_constants_vs_oracle(qd, orc, load):
         m = orc.build_model(raw[i])
         want = dict(m0=m.m0, c0z=m.c0[2], I0x=m.I0full[0], I0y=m.I0full[1], I0z=m.I0full[2], rot=m.rotor[1][0],
                     gearF=m.gearF, gearT=m.gearT[0], inv_tau=1 / m.tau, m2=m.m2, lc=m.lc, I2t=m.I2[0], I2a=m.I2[2])
+        want.update(fluid_coeffs(m.I0full[0], m.I0full[1], m.I0full[2], m.m0, "0"))
+        if load:
+            want.update(fluid_coeffs(m.I2[0], m.I2[1], m.I2[2], m.m2, "2"))
         for k, v in want.items():
             assert abs(mc[k][i] - v) <= 2e-7 * abs(v) + 1e-30, (i, k, mc[k][i], v)
 
@@ -326,7 +343,7 @@ def test_reset_sampling_statistics(qd):
     assert r.max() <= 0.8 + 1e-5
     assert abs(np.mean((r / 0.8) ** 3) - 0.5) < 0.03          # r^3 uniform
     assert np.abs(v[:, :6]).max() <= 0.8 + 1e-6                 # clipped at 2 sigma
-    assert abs(np.std(v[:, 0]) - 0.4 * 0.8796) < 0.02           # std of a normal clipped at 2 sigma
+    assert abs(np.std(v[:, 0]) - 0.4 * 0.9594) < 0.02           # std of a normal clipped (not truncated) at 2 sigma
     assert np.allclose(np.linalg.norm(q[:, 3:7], axis=1), 1, atol=1e-6)
     yaw = 2 * np.arctan2(q[:, 6], q[:, 3])
     assert abs(np.mean(np.cos(yaw))) < 0.05 and abs(np.mean(np.sin(yaw))) < 0.05
@@ -360,12 +377,13 @@ def test_rollout_equals_steps(qd, load):
     O, R, Tr = a.rollout(acts)
     for t in range(T):
         o, r, tr = b.step(acts[t])
-        np.testing.assert_allclose(O[t].cpu().numpy(), o.cpu().numpy(), rtol=1e-5, atol=1e-5)
-        np.testing.assert_allclose(R[t].cpu().numpy(), r.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        # two different kernels: the compiler may contract/schedule the same arithmetic differently
+        np.testing.assert_allclose(O[t].cpu().numpy(), o.cpu().numpy(), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(R[t].cpu().numpy(), r.cpu().numpy(), rtol=1e-4, atol=1e-4)
         assert torch.equal(Tr[t], tr)
     assert int(Tr[4].sum()) == n and int(Tr[9].sum()) == n      # max_steps = 5 -> every env truncates at t = 4, 9
     for x, y in zip(a.get_state(), b.get_state()):
-        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-5, atol=1e-5)
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), rtol=1e-4, atol=1e-4)
 
 
 def test_auto_reset_resamples_truncated_envs(qd, orc):
@@ -404,7 +422,8 @@ def test_full_size_independence_and_invariants(qd):
     q, v, a, s, k = big.get_state()
     assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(s).all()
     assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(4096, device=q.device), atol=1e-5)
-    assert float(a.min()) >= 0.0 and float(a.max()) <= 1.0 + 1e-6
+    # activations are NOT confined to [0,1]: the explicit-Euler filter overshoots when h/tau > 1 (QUIRK C-11)
+    assert float(a.min()) >= -0.5 and float(a.max()) <= 1.5
     assert torch.all(k == T)
 
 
