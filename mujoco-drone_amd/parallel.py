@@ -73,7 +73,9 @@ class FragmentGather:
             return self.out, []
         works = []
         for k, t in frag.tensors().items():
-            works.append(dist.all_gather_into_tensor(self.out[k], t, async_op=async_op))
+            # concatenated form [world*T, N, ...] of the same buffer: accepted by both RCCL and gloo
+            flat = self.out[k].view((self.world * t.shape[0],) + tuple(t.shape[1:]))
+            works.append(dist.all_gather_into_tensor(flat, t, async_op=async_op))
         return self.out, [w for w in works if w is not None]
 
     def learner_view(self):

@@ -88,3 +88,35 @@ void twin_simple_obs(const double* qpos, double* out) {
   simple_obs<double>(s, out);
 }
 }
+
+// ---- fused-kernel variants: attitude matrix taken from the quaternion ----
+static State<double> mk_state(const double* qpos, const double* qvel, const double* act) {
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = qpos[7]; s.th2 = qpos[8];
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = qvel[6]; s.thd2 = qvel[7];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  return s;
+}
+extern "C" {
+int twin_obs_q(int kind, const double* qpos, const double* qvel, const double* sens, const double* act, const double* ref,
+               const double* par, double* out) {
+  State<double> s = mk_state(qpos, qvel, act);
+  double sv[33];
+  M3<double> Rq;
+  drone_state<double, true>(s, mk<double>(sens[0], sens[1], sens[2]), ref, par, sv, &Rq);
+  int n = -1;
+#define CALLQ(K) n = observe<double, 33, K>(sv, ref, out, &Rq)
+  QD_OBS_DISPATCH(kind, CALLQ)
+  return n;
+}
+double twin_reward_q(int kind, const double* qpos, const double* qvel, const double* sens, const double* act,
+                     const double* ref, const double* par, const double* a, int k, double max_distance) {
+  State<double> s = mk_state(qpos, qvel, act);
+  double sv[33];
+  M3<double> Rq;
+  drone_state<double, true>(s, mk<double>(sens[0], sens[1], sens[2]), ref, par, sv, &Rq);
+  return reward<double>(kind, sv, a, k, ref, max_distance, &Rq);
+}
+}

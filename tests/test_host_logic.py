@@ -1,0 +1,128 @@
+"""Host-side mirror of the reference interface: config keys, class and function names, selection of device
+kernels by name, loud failure without a GPU.  No GPU needed."""
+import json
+
+import numpy as np
+import pytest
+
+
+def test_base_config_equals_reference(golden):
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    ref = json.loads(str(golden["base_config_json"]))
+    mine = {k: v for k, v in base_config.items() if not callable(v)}
+    assert mine == ref
+    assert base_config["reward_fcn"].__name__ == str(golden["base_config_reward_fcn"])
+    assert base_config["terminated_fcn"].__name__ == str(golden["base_config_terminated_fcn"])
+
+
+def test_reward_registry_and_resolution():
+    from mujoco_drone_amd import _lib as L
+    from mujoco_drone_amd.environments import rewards
+    for k, name in enumerate(L.REWARD_KINDS[:17]):
+        f = getattr(rewards, name)
+        assert f.__name__ == name and rewards.resolve(f) == k and rewards.resolve(name) == k
+
+    def distance_energy_reward(env, state, action, num_steps):   # a foreign callable with a known name
+        return 0.0
+    assert rewards.resolve(distance_energy_reward) == 2
+    with pytest.raises(TypeError):
+        rewards.resolve(lambda env, s, a, k: 0.0)
+
+
+def test_observation_wrapper_classes_mirror_reference():
+    from mujoco_drone_amd import _lib as L
+    from mujoco_drone_amd.environments import observation_wrappers as ow
+    from mujoco_drone_amd.environments.BaseDroneEnv import BaseDroneEnv
+    names = ["GlobalFrameRPYEnv", "LocalFramePRYEnv", "LocalFrameFullStateEnv", "LocalFrameFullStateZvecEnv",
+             "LocalFramePRYaccEnv", "LocalFramePRYParamsEnv", "LocalFramePRYaccParamsEnv", "LocalFrameRPYParamsEnv",
+             "LocalFrameRPYFakeParamsEnv", "LocalFrameRPYEnv", "LocalFramePRYaccNoPendEnv",
+             "LocalFramePRYaccParamsNoPendEnv", "LocalFrameRmParamsEnv", "LocalFrameZvecEnv"]
+    for n in names:
+        cls = getattr(ow, n)
+        assert issubclass(cls, BaseDroneEnv) and cls.OBS_KIND == L.OBS_KINDS.index(n)
+    assert BaseDroneEnv.OBS_KIND == 0
+    for m in ("vector_reset", "reset_at", "vector_step", "reset_model", "get_drone_states", "set_state", "move_mocap_to",
+              "render", "close", "reset", "_get_obs"):
+        assert callable(getattr(BaseDroneEnv, m))
+
+
+def test_no_cpu_fallback():
+    """the product path must fail loudly when it cannot run on the GPU"""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from mujoco_drone_amd.environments.BaseDroneEnv import BaseDroneEnv, base_config
+    from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
+    from mujoco_drone_amd.environments import transformation, rewards
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        BaseDroneEnv(dict(base_config, num_drones=4))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        SimpleDrone(num_drones=1)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        transformation.mujoco_rpy2quat([0.1, -0.2, 0.3])
+    import types
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        rewards.default_reward_fcn(types.SimpleNamespace(reference=[0, 0, 0, 0], max_distance=4), np.zeros(33), np.zeros(4), 0)
+
+
+def test_product_does_not_import_the_oracle():
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, "mujoco-drone_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert "oracle" not in text.replace("the general oracle", "").replace("float64 oracle", "").replace(
+                    "reference oracle", ""), os.path.join(dirpath, f)
+
+
+def test_config_translation_without_device(monkeypatch):
+    """BaseDroneEnv.__init__ key handling (BaseDroneEnv.py:60-106) up to the device hand-off"""
+    from mujoco_drone_amd.environments import BaseDroneEnv as B
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv, LocalFramePRYaccParamsNoPendEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward, reward_2
+    seen = {}
+
+    class FakeDev:
+        def __init__(self, cfg, device):
+            seen["cfg"] = cfg
+            self.D, self.nq, self.nv = 22, 9, 8
+            raise InterruptedError  # stop before any device use
+
+    monkeypatch.setattr(B, "DeviceEnv", FakeDev)
+    cfg = dict(B.base_config, num_drones=7, reward_fcn=distance_energy_reward, state_difficulty=0.2, param_difficulty=1,
+               max_steps=1024, angle_variance=[0.5, 0.25], seed=42)
+    with pytest.raises(InterruptedError):
+        LocalFrameRPYParamsEnv(cfg)
+    c = seen["cfg"]
+    assert (c.num_envs, c.model, c.obs_kind, c.reward_kind) == (7, 1, 8, 2)
+    assert (c.frame_skip, c.max_steps, c.ctrl_map, c.term_kind, c.random_start, c.random_params) == (1, 1024, 1, 0, 1, 1)
+    assert abs(c.timestep - 0.01) < 1e-15 and c.max_distance == 4.0
+    assert list(c.reference) == [0, 0, 15, 0] and list(c.start_pos) == [0, 0, 15, 0]
+    assert abs(c.max_pos_offset - 0.4) < 1e-15                      # state_difficulty * max_random_offset
+    np.testing.assert_allclose(list(c.angle_var), [0.1, 0.05])      # 'angle_variance', not base_config's 'rp_variance'
+    np.testing.assert_allclose(list(c.vel_var), [0.2] * 3)
+    np.testing.assert_allclose(list(c.pend_rp_var), [0.1] * 2)
+    np.testing.assert_allclose(list(c.param_center), [1, 0.17, 7, 0.01, 1.2, 0.3])
+    np.testing.assert_allclose(list(c.param_width), [0.1, 0.02, 1, 0.0025, 0.2, 0.05])
+    assert c.param_difficulty == 1.0
+    assert c.seed == 42                                             # worker_index is looked up as a dict key -> +0
+    with pytest.raises(InterruptedError):
+        B.BaseDroneEnv(dict(cfg, worker_index=3))
+    assert seen["cfg"].seed == 46
+    with pytest.raises(InterruptedError):
+        B.BaseDroneEnv({})                                          # the reference's .get defaults
+    c = seen["cfg"]
+    assert (c.num_envs, c.model, c.obs_kind, c.random_start, c.random_params, c.max_steps) == (1, 1, 0, 0, 0, 512)
+    assert abs(c.timestep - 1 / 200) < 1e-15 and c.max_distance == 1.0 and c.seed == 1
+    np.testing.assert_allclose(list(c.param_center), [1.35, 0.17, 7.5, 0.003, 1.2, 0.2])
+    # errors the reference raises for the same configurations
+    with pytest.raises(NameError):
+        LocalFramePRYaccParamsNoPendEnv(cfg)
+    with pytest.raises(IndexError):
+        B.BaseDroneEnv(dict(cfg, pendulum=False, reward_fcn=reward_2))
+    with pytest.raises(TypeError):
+        B.BaseDroneEnv(dict(cfg, terminated_fcn=lambda *a: False))
+    with pytest.raises(TypeError):
+        B.BaseDroneEnv(dict(cfg, reward_fcn=lambda *a: 0.0))

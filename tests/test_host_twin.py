@@ -1,0 +1,171 @@
+"""The product's templated device headers (csrc/qd_{model,dynamics,obsrew}.h) instantiated on the HOST by a
+test-only harness (tests/host_twin), so that the specialised body-frame derivation the HIP kernels run can be
+compared with the general world-frame oracle at 1e-9 here, without a GPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CENTER = np.array([1, 0.17, 7, 0.01, 1.2, 0.3])
+WIDTH = np.array([0.1, 0.02, 1, 0.0025, 0.2, 0.05])
+dp = C.POINTER(C.c_double)
+
+
+def P(a):
+    return a.ctypes.data_as(dp)
+
+
+@pytest.fixture(scope="module")
+def twin():
+    out = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(out, exist_ok=True)
+    so = os.path.join(out, "qd_host_twin.so")
+    src = os.path.join(ROOT, "tests", "host_twin", "qd_host_twin.cpp")
+    inc = os.path.join(ROOT, "mujoco-drone_amd", "csrc")
+    deps = [src] + [os.path.join(inc, f) for f in os.listdir(inc) if f.endswith(".h")]
+    if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off", "-I", inc, "-o", so, src])
+    lib = C.CDLL(so)
+    lib.twin_reward.restype = C.c_double
+    lib.twin_reward_q.restype = C.c_double
+    lib.twin_round5.restype = C.c_double
+    lib.twin_round5.argtypes = [C.c_double]
+    return lib
+
+
+def rand_raw(rng, load):
+    r = CENTER + rng.uniform(-1, 1, 6) * WIDTH
+    if not load:
+        r[4:] = 0
+    return r
+
+
+def test_round5_matches_printf_round_trip(twin, orc):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([rng.uniform(-3, 3, 20000), 10.0 ** rng.uniform(-6, 4, 20000), [0.0, 1.0, 0.1, 0.015, 2e-5, 0.785398163]])
+    for x in xs:
+        assert twin.twin_round5(float(x)) == orc.round5g(float(x)), x
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_closed_form_model_vs_general_geom_composition(twin, orc, load):
+    rng = np.random.default_rng(1)
+    for _ in range(300):
+        raw = rand_raw(rng, load)
+        m = orc.build_model(raw)
+        m28 = np.zeros(28)
+        assert twin.twin_derive(P(raw), P(m28)) == load
+        want = [m.m0, m.c0[2], m.I0full[0], m.I0full[1], m.I0full[2], m.rotor[1][0], m.gearF, m.gearT[0], 1 / m.tau]
+        np.testing.assert_allclose(m28[:9], want, rtol=1e-12)
+        np.testing.assert_allclose(m28[17:21], [m.m2, m.lc, m.I2[0], m.I2[2]], rtol=1e-12, atol=1e-300)
+        # symmetry facts the closed form relies on
+        assert max(abs(m.I0full[3]), abs(m.I0full[4]), abs(m.I0full[5])) < 1e-12
+        assert abs(m.c0[0]) < 1e-15 and abs(m.c0[1]) < 1e-15
+        rot = np.array([[m.rotor[i][j] for j in range(3)] for i in range(4)])
+        np.testing.assert_array_equal(np.abs(rot[:, :2]), np.full((4, 2), m.rotor[1][0]))
+        assert list(np.sign(rot[:, 0])) == [1, 1, -1, -1] and list(np.sign(rot[:, 1])) == [-1, 1, 1, -1]
+        assert list(np.sign(m.gearT[:])) == [1, -1, 1, -1]
+        # MuJoCo's principal frame of the core is a signed axis permutation (so body-axis drag is exact)
+        R0 = np.array(m.R0i[:]).reshape(3, 3)
+        assert np.allclose(np.sort(np.abs(R0).ravel()), [0] * 6 + [1] * 3, atol=1e-9)
+        # fluid coefficients against the oracle's box dimensions, permuted back to body axes
+        perm = np.argmax(np.abs(R0), axis=0)          # inertial axis k lies along body axis perm[k]
+        box = np.zeros(3); box[perm] = np.array(m.box0[:])
+        d = box.mean()
+        np.testing.assert_allclose(m28[9:11], [3 * np.pi * d * 2e-5, np.pi * d ** 3 * 2e-5], rtol=1e-10)
+        np.testing.assert_allclose(m28[11:14], [0.6 * box[1] * box[2], 0.6 * box[0] * box[2], 0.6 * box[0] * box[1]], rtol=1e-10)
+        np.testing.assert_allclose(m28[14:17], [1.2 * box[i] * (box[(i + 1) % 3] ** 4 + box[(i + 2) % 3] ** 4) / 64 for i in range(3)], rtol=1e-10)
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_specialised_dynamics_vs_general_oracle_f64(twin, orc, load):
+    rng = np.random.default_rng(2)
+    worst = 0.0
+    for _ in range(200):
+        raw = rand_raw(rng, load)
+        m = orc.build_model(raw)
+        m28 = np.zeros(28); twin.twin_derive(P(raw), P(m28))
+        nq, nv = (9, 8) if load else (7, 6)
+        qpos = np.zeros(nq); qpos[:3] = [0, 0, 15] + rng.normal(size=3)
+        q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q)
+        if load:
+            qpos[7:] = rng.normal(scale=0.6, size=2)
+        qvel = rng.normal(scale=1.5, size=nv)
+        act, ctrl = rng.uniform(0, 1, 4), rng.uniform(-0.1, 1.1, 4)
+        want = orc.step(m, 0.01, 3, qpos, qvel, act, ctrl)
+        a, b, c, s = qpos.copy(), qvel.copy(), act.copy(), np.zeros(3)
+        twin.twin_step_f64(load, P(m28), P(a), P(b), P(c), P(ctrl), C.c_double(0.01), 3, P(s))
+        worst = max(worst, *(np.abs(g - w).max() for g, w in zip((a, b, c, s), want)))
+    assert worst < 1e-9, worst
+
+
+def test_float32_device_arithmetic_200_step_divergence(twin, orc):
+    """what the GPU computes, predicted on the CPU: float32 state / trig / drag / integration with the
+    float64 algebra core, 200 steps of random rotor commands, against the float64 oracle.  Target <= 1e-4."""
+    rng = np.random.default_rng(5)
+    worst = 0.0
+    for i in range(24):
+        raw = rand_raw(rng, 1)
+        m = orc.build_model(raw)
+        m28 = np.zeros(28); twin.twin_derive(P(raw), P(m28))
+        qpos = np.zeros(9); qpos[:3] = [0, 0, 15] + rng.normal(size=3); qpos[3] = 1; qpos[7:] = rng.normal(scale=0.2, size=2)
+        qvel = rng.normal(scale=0.4, size=8)
+        f32 = lambda x: x.astype(np.float32).astype(np.float64)
+        a, b, c, s = f32(qpos), f32(qvel), np.zeros(4), np.zeros(3)
+        oq, ov, oa = a.copy(), b.copy(), c.copy()
+        for t in range(200):
+            ctrl = f32(0.1 + 0.9 * rng.uniform(0, 1, 4))
+            oq, ov, oa, _ = orc.step(m, 0.01, 1, oq, ov, oa, ctrl)
+            twin.twin_step_f32(1, P(m28), P(a), P(b), P(c), P(ctrl), C.c_double(0.01), 1, P(s))
+            a, b, c = f32(a), f32(b), f32(c)
+        for g, w in ((a, oq), (b, ov), (c, oa)):
+            worst = max(worst, float(np.max(np.abs(g - w) / np.maximum(1, np.abs(w)))))
+    assert worst < 1e-4, worst
+
+
+def test_observation_reward_headers_vs_golden(twin, golden, orc):
+    ref, A, K = golden["st_ref"], golden["st_actions"], golden["st_num_steps"]
+    for tag in ("33", "29"):
+        S = golden["st" + tag]
+        for kind in range(15):
+            name = orc.OBS_KINDS[kind]
+            if kind == 12:
+                continue
+            key = "obs%s_%s" % (tag, name)
+            for i in range(len(S)):
+                out = np.zeros(40)
+                n = twin.twin_obs(kind, P(np.ascontiguousarray(S[i])), int(tag), P(ref), P(out))
+                want = golden[key][i] if kind > 0 else S[i]
+                assert n == len(want) == twin.twin_obs_dim(kind, int(tag))
+                np.testing.assert_allclose(out[:n], want, atol=1e-11)
+    S = golden["st33"]
+    for kind, name in enumerate(orc.REWARD_KINDS[:17]):
+        got = [twin.twin_reward(kind, P(np.ascontiguousarray(S[i])), P(np.ascontiguousarray(A[i])), int(K[i]), P(ref),
+                                C.c_double(4.0)) for i in range(len(S))]
+        np.testing.assert_allclose(got, golden["rew_" + name], rtol=1e-10, atol=1e-10)
+    tr = [bool(twin.twin_truncated(P(np.ascontiguousarray(S[i])), P(ref), int(K[i]), C.c_double(4.0), 512)) for i in range(len(S))]
+    assert tr == list(golden["trunc33"])
+
+
+def test_quaternion_matrix_fast_path_equals_rpy_path(twin, orc):
+    """fused kernels take the attitude matrix from the quaternion instead of rebuilding it from roll/pitch/yaw"""
+    rng = np.random.default_rng(9)
+    ref = np.array([0.3, -0.2, 15.0, 0.7])
+    for _ in range(50):
+        qpos = np.zeros(9); qpos[:3] = [0, 0, 15] + rng.normal(size=3)
+        q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q); qpos[7:] = rng.normal(scale=0.5, size=2)
+        qvel, sens, act, par = rng.normal(size=8), rng.normal(size=3), rng.uniform(0, 1, 4), CENTER.copy()
+        s = orc.drone_state(1, qpos, qvel, sens, act, ref, par)
+        a = rng.uniform(0, 1, 4)
+        for kind in range(1, 15):
+            if kind == 12:
+                continue
+            out = np.zeros(40)
+            n = twin.twin_obs_q(kind, P(qpos), P(qvel), P(sens), P(act), P(ref), P(par), P(out))
+            np.testing.assert_allclose(out[:n], orc.obs(kind, s, ref), atol=1e-9, err_msg=str(kind))
+        for kind in range(17):
+            got = twin.twin_reward_q(kind, P(qpos), P(qvel), P(sens), P(act), P(ref), P(par), P(a), 37, C.c_double(4.0))
+            assert abs(got - orc.reward(kind, s, a, 37, ref, 4.0)) < 1e-9, kind

@@ -1,0 +1,120 @@
+"""Physical-invariant checks of the oracle's physics step (the part no reference fixture
+pins: "parity unpinned").  They hold for any correct implementation of the equations of
+motion and the first-order integrator, independently of MuJoCo."""
+import numpy as np
+import pytest
+
+RAW = np.array([1.0, 0.17, 7.0, 0.01, 1.2, 0.3])
+
+
+def _model(orc, load, free=False):
+    r = RAW.copy()
+    if not load:
+        r[4:] = 0
+    m = orc.build_model(r)
+    if free:
+        m.density = m.viscosity = m.damping = m.gravity = 0.0
+    return m
+
+
+def _state(load, rng):
+    nq, nv = (9, 8) if load else (7, 6)
+    qpos = np.zeros(nq); qpos[2] = 15
+    q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q)
+    if load:
+        qpos[7:] = [0.5, -0.4]
+    return qpos, rng.normal(size=nv)
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_mass_matrix_symmetric_positive_definite(orc, load):
+    rng = np.random.default_rng(0)
+    m = _model(orc, load)
+    for _ in range(20):
+        qpos, _ = _state(load, rng)
+        M = orc.mass_matrix(m, qpos)
+        np.testing.assert_allclose(M, M.T, atol=1e-14)
+        assert np.linalg.eigvalsh(M).min() > 0
+        mt = m.m0 + (m.m1 + m.m2 if load else 0)
+        np.testing.assert_allclose(M[:3, :3], mt * np.eye(3), atol=1e-13)
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_momentum_and_energy_conservation_first_order(orc, load):
+    """no gravity / drag / damping / thrust: momenta and kinetic energy are conserved up to the O(h) error of
+    the semi-implicit Euler scheme, i.e. the drift shrinks ~4x when h shrinks 4x"""
+    rng = np.random.default_rng(1)
+    m = _model(orc, load, free=True)
+    qpos0, qvel0 = _state(load, rng)
+    drift = []
+    for h in (1e-3, 2.5e-4):
+        qp, qv, act = qpos0.copy(), qvel0.copy(), np.zeros(4)
+        ke0, _, l0, a0 = orc.energy_momentum(m, qp, qv)
+        for _ in range(int(round(0.5 / h))):
+            qp, qv, act, _ = orc.step(m, h, 1, qp, qv, act, np.zeros(4))
+        ke, _, l, a = orc.energy_momentum(m, qp, qv)
+        drift.append((abs(ke - ke0) / ke0, np.abs(l - l0).max(), np.abs(a - a0).max()))
+    for d1, d2 in zip(*drift):
+        assert d2 < d1 * 0.3 + 1e-12
+    assert drift[1][0] < 1e-5 and drift[1][1] < 1e-4 and drift[1][2] < 1e-4
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_free_fall_and_gravity_impulse(orc, load):
+    rng = np.random.default_rng(2)
+    m = _model(orc, load)
+    m.density = m.viscosity = m.damping = 0.0
+    nq, nv = (9, 8) if load else (7, 6)
+    qp = np.zeros(nq); qp[2] = 15; qp[3] = 1
+    qacc, _, sens = orc.forward(m, qp, np.zeros(nv), np.zeros(4), np.zeros(4))
+    np.testing.assert_allclose(qacc[:3], [0, 0, -9.81], atol=1e-12)
+    np.testing.assert_allclose(sens, 0, atol=1e-12)                       # an accelerometer in free fall reads zero
+    qpos0, qvel0 = _state(load, rng)
+    mt = m.m0 + (m.m1 + m.m2 if load else 0)
+    h, n = 2.5e-4, 2000
+    qp, qv, act = qpos0.copy(), qvel0.copy(), np.zeros(4)
+    _, _, l0, _ = orc.energy_momentum(m, qp, qv)
+    for _ in range(n):
+        qp, qv, act, _ = orc.step(m, h, 1, qp, qv, act, np.zeros(4))
+    _, _, l, _ = orc.energy_momentum(m, qp, qv)
+    np.testing.assert_allclose(l - l0, [0, 0, -mt * 9.81 * h * n], atol=2e-4)
+
+
+@pytest.mark.parametrize("load", [1, 0])
+def test_hover_equilibrium_and_accelerometer(orc, load):
+    m = _model(orc, load)
+    nq, nv = (9, 8) if load else (7, 6)
+    mt = m.m0 + (m.m1 + m.m2 if load else 0)
+    a_h = mt * 9.81 / (4 * m.gearF)
+    qp = np.zeros(nq); qp[2] = 15; qp[3] = 1
+    qacc, act_dot, sens = orc.forward(m, qp, np.zeros(nv), np.full(4, a_h), np.full(4, a_h))
+    assert np.abs(qacc).max() < 1e-12 and np.abs(act_dot).max() < 1e-12
+    np.testing.assert_allclose(sens, [0, 0, 9.81], atol=1e-12)           # at rest the sensor reads +g
+
+
+def test_actuator_filter_and_yaw_torque_signs(orc):
+    m = _model(orc, 0)
+    qp = np.zeros(7); qp[2] = 15; qp[3] = 1
+    # activations follow ctrl with time constant tau, explicit Euler: act += h (ctrl - act) / tau
+    _, _, act, _ = orc.step(m, 0.001, 1, qp, np.zeros(6), np.zeros(4), np.array([1, 0.5, 2.0, -1.0]))
+    np.testing.assert_allclose(act, 0.001 / m.tau * np.array([1, 0.5, 1.0, 0.0]), atol=1e-15)  # ctrl clamped to [0,1]
+    # rotor 0 only: positive yaw torque (gear +F/100), roll/pitch torque from its position (+x, -y)
+    qacc, _, _ = orc.forward(m, qp, np.zeros(6), np.array([1.0, 0, 0, 0]), np.zeros(4))
+    assert qacc[5] > 0 and qacc[3] < 0 and qacc[4] < 0
+    # h / tau > 1 overshoots (reference quirk C-11): act leaves [0,1]
+    _, _, act, _ = orc.step(m, 0.0133, 1, qp, np.zeros(6), np.ones(4), np.zeros(4))
+    assert act.min() < 0
+
+
+def test_model_matches_closed_forms(orc):
+    """total mass, COM, and the tether stack of the default parameters, from env_gen.py by hand"""
+    m = orc.build_model([1.35, 0.15, 7.5, 0.015, 1.2, 0.3])
+    assert abs(m.m0 - (0.756 + 4 * 0.0945 + 4 * 0.054)) < 1e-12
+    assert abs(m.c0[2] - 4 * 0.054 * 0.015 / m.m0) < 1e-15 and abs(m.c0[0]) < 1e-15 and abs(m.c0[1]) < 1e-15
+    assert abs(m.m2 - (0.24 + 0.3)) < 1e-12
+    assert abs(m.lc - (0.24 * 0.6 + 0.3 * 1.2) / 0.54) < 1e-12
+    assert m.gearF == 7.5 and list(m.gearT) == [0.075, -0.075, 0.075, -0.075] and m.tau == 0.015
+    # Ixx and Iyy differ by ~2.6e-9: the 5-digit Euler angles of arms 2 and 3 (2.3562, 3.927) are not exact
+    assert 1e-10 < abs(m.I0full[0] - m.I0full[1]) < 1e-8 and m.I0full[2] > m.I0full[0]
+    assert max(abs(m.I0full[3]), abs(m.I0full[4]), abs(m.I0full[5])) < 1e-12
+    assert orc.round5g(0.123456789) == 0.12346 and orc.round5g(-1234.5678) == -1234.6 and orc.round5g(2e-5) == 2e-5
