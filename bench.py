@@ -182,8 +182,11 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
+    ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
     run(K, base=W)
+    ev1.record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -209,8 +212,12 @@ def main():
                           "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 1 if args.config == "config3" else 2,
                           "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
-        kus, raw_us, empty_us = kernel_time_us(env, actions)
-        period_us = stream_rate_us(env, actions)
+        # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
+        # back-to-back launches (the regen launches every 1024 steps are < 0.1 % of it), so elapsed / K is the
+        # kernel's average duration including the inter-kernel boundary -- the same quantity rocprofv3's kernel
+        # trace reports for back-to-back dispatches (profiles/r01_n4096_rocprof_summary.json)
+        kus = ev0.elapsed_time(ev1) * 1e3 / K
+        iso_us, raw_us, empty_us = kernel_time_us(env, actions)
         bytes_per_launch = ALG_BYTES[alg] * n
         achieved = bytes_per_launch / (kus * 1e-6) / 1e9
         traffic = None
@@ -222,11 +229,11 @@ def main():
                 traffic = None
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
-                           "kernel_us": kus, "event_pair_us": raw_us, "empty_event_pair_us": empty_us,
-                           "back_to_back_period_us": period_us, "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
-                           "env_steps_per_launch": n,
+                           "kernel_us": kus, "isolated_launch_us": iso_us, "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
+                           "env_steps_per_launch": n, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                           "WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
                            "note": "4096 envs = 64 wavefronts on 1024 SIMDs: the launch is latency/occupancy-bound, "
-                                   "not HBM-bound (see DESIGN.md and the N sweep in `extras`)"}
+                                   "not HBM-bound (see DESIGN.md and the env-count sweep in `extras`)"}
         if not args.no_extras and world == 1:
             extras = {}
             try:

@@ -63,6 +63,29 @@ struct EnvRegs {  // everything one lane keeps in registers for one env
 };
 constexpr uint32_t FLAG_ACC_STALE = 1u;
 
+// Compile-time specialisations of the fused step for the configurations the reference trains with; every other
+// configuration runs the generic instantiation, which dispatches on the KArgs fields at run time (wave-uniform
+// branches).  Specialising removes the dispatch chains and lets the compiler drop state-vector entries the
+// selected observation / reward never reads.
+enum Spec {
+  SPEC_GENERIC = 0,
+  SPEC_RMA = 1,     // train_PPO.py / train_RMA.py: LocalFrameRPYParamsEnv + distance_energy_reward      (BASELINE cfg 3, 4)
+  SPEC_LSTM = 2,    // train_LSTM.py: LocalFrameFullStateEnv + distance_energy_reward_pendulum_en4          (BASELINE cfg 5)
+  SPEC_SIMPLE = 3   // SimpleDrone.py: 6-value observation, drone-0 style reward / termination, direct ctrl (BASELINE cfg 1, 2)
+};
+template <int SPEC> __device__ __forceinline__ int spec_obs(const KArgs& a) {
+  return SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : SPEC == SPEC_LSTM ? (int)OBS_FULLSTATE : SPEC == SPEC_SIMPLE ? (int)OBS_SIMPLE : a.obs_kind;
+}
+template <int SPEC> __device__ __forceinline__ int spec_reward(const KArgs& a) {
+  return SPEC == SPEC_RMA ? (int)REW_DISTANCE_ENERGY : SPEC == SPEC_LSTM ? (int)REW_PEND_EN4 : SPEC == SPEC_SIMPLE ? (int)REW_SIMPLE : a.reward_kind;
+}
+template <int SPEC> __device__ __forceinline__ int spec_term(const KArgs& a) {
+  return SPEC == SPEC_SIMPLE ? (int)QD_TERM_SIMPLE : SPEC == SPEC_GENERIC ? a.term_kind : (int)QD_TERM_DEFAULT;
+}
+template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
+  return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : SPEC == SPEC_GENERIC ? a.ctrl_map : (int)QD_CTRL_AFFINE;
+}
+
 template <bool LOAD>
 __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   const float4* g = a.g;
@@ -152,19 +175,22 @@ __device__ __forceinline__ void obs_to_lds(const float* sv, const float ref[4], 
     if (k < n) row[k] = o[k];
 }
 
-template <bool LOAD>
+template <bool LOAD, int SPEC>
 __device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, const float* sv, const M3<float>* Rq,
                                               float* row) {
   constexpr int NS = LOAD ? 33 : 29;
-  if (a.obs_kind == OBS_SIMPLE) {
+  const int kind = spec_obs<SPEC>(a);
+  if (kind == OBS_SIMPLE) {
     float o[6];
     simple_obs<float>(e.s, o);
 #pragma unroll
     for (int k = 0; k < 6; k++) row[k] = o[k];
     return;
   }
+  if (SPEC == SPEC_RMA) { obs_to_lds<NS, OBS_RPY_PARAMS>(sv, e.ref, row, Rq); return; }
+  if (SPEC == SPEC_LSTM) { obs_to_lds<NS, OBS_FULLSTATE>(sv, e.ref, row, Rq); return; }
 #define QD_CALL(K) obs_to_lds<NS, K>(sv, e.ref, row, Rq)
-  QD_OBS_DISPATCH(a.obs_kind, QD_CALL)
+  QD_OBS_DISPATCH(kind, QD_CALL)
 #undef QD_CALL
 }
 
@@ -178,6 +204,29 @@ __device__ __forceinline__ void flush_obs(const float* tile, float* dst, int row
 #pragma unroll 3
   for (int j = lane; j < n4; j += 64) d4[j] = t4[j];
   for (int j = (n4 << 2) + lane; j < total; j += 64) dst[j] = tile[j];
+}
+
+// full wavefront, row length known at compile time: all LDS reads are issued before the first store
+template <int D>
+__device__ __forceinline__ void flush_obs_static(const float* tile, float* dst) {
+  constexpr int N4 = 16 * D, IT = (N4 + 63) / 64;
+  const int lane = threadIdx.x & 63;
+  const float4* t4 = reinterpret_cast<const float4*>(tile);
+  float4* d4 = reinterpret_cast<float4*>(dst);
+  float4 v[IT];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (lane + 64 * k < N4) v[k] = t4[lane + 64 * k];
+#pragma unroll
+  for (int k = 0; k < IT; k++)
+    if (lane + 64 * k < N4) d4[lane + 64 * k] = v[k];
+}
+template <int SPEC> constexpr int spec_obs_dim() { return SPEC == SPEC_RMA ? 22 : SPEC == SPEC_LSTM ? 23 : SPEC == SPEC_SIMPLE ? 6 : 0; }
+
+template <int SPEC>
+__device__ __forceinline__ void flush_obs_any(const float* tile, float* dst, int rows, int D) {
+  if (SPEC != SPEC_GENERIC && rows == 64) flush_obs_static<(spec_obs_dim<SPEC>() > 0 ? spec_obs_dim<SPEC>() : 4)>(tile, dst);
+  else flush_obs(tile, dst, rows, D);
 }
 
 #ifdef QD_STAMPS
@@ -197,12 +246,12 @@ __device__ unsigned long long qd_rstamps[64 * 2];
 #endif
 
 // ---- one full env step for the lane's env (everything after the state is in registers) ----
-template <bool LOAD>
+template <bool LOAD, int SPEC>
 __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, float4 action, float* obs_row, float* rew,
                                          uint8_t* trunc) {
   constexpr int NS = LOAD ? 33 : 29;
   float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
-  if (a.ctrl_map == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+  if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
   for (int k = 0; k < a.frame_skip; k++) e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
   QD_STAMP(2);
@@ -213,7 +262,8 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   M3<float> Rq;
   bool tr;
   float r;
-  if (a.term_kind == QD_TERM_SIMPLE) {
+  const int term_kind = spec_term<SPEC>(a);
+  if (term_kind == QD_TERM_SIMPLE) {
     // SimpleDrone.step: terminated = |pos - ref| > 0.5, reward = 0.1 - |pos - ref| (SimpleDrone.py:57-60)
     const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
     const float d = qsqrt(dx * dx + dy * dy + dz * dz);
@@ -222,20 +272,20 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   } else {
     drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
     tr = truncated<float>(sv, e.ref, e.num_steps, a.max_distance, a.max_steps);
-    r = reward<float>(a.reward_kind, sv, act4, e.num_steps, e.ref, a.max_distance, &Rq);
+    r = reward<float>(spec_reward<SPEC>(a), sv, act4, e.num_steps, e.ref, a.max_distance, &Rq);
   }
   if (a.auto_reset && tr) {
     resample<LOAD>(a, i, e, a.obs_needs_acc != 0);
-    if (a.term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
+    if (term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
   *rew = r;
   *trunc = tr ? 1 : 0;
   QD_STAMP(3);
-  write_obs_row<LOAD>(a, e, sv, &Rq, obs_row);
+  write_obs_row<LOAD, SPEC>(a, e, sv, &Rq, obs_row);
   (void)NS;
 }
 
-template <bool LOAD, int BLOCK>
+template <bool LOAD, int BLOCK, int SPEC>
 __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
@@ -257,7 +307,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict
 #endif
     float r;
     uint8_t t;
-    env_step<LOAD>(a, i, e, action, wtile + lane * a.D, &r, &t);
+    env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &t);
     QD_STAMP(4);
     store_env(a, i, e);
     reward[i] = r;
@@ -268,7 +318,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict
   QD_STAMP(5);
   if (wave_base < a.n) {
     const int rows = min(64, a.n - wave_base);
-    flush_obs(wtile, obs + (size_t)wave_base * a.D, rows, a.D);
+    flush_obs_any<SPEC>(wtile, obs + (size_t)wave_base * a.D, rows, a.D);
   }
   QD_STAMP(6);
 #ifdef QD_STAMPS
@@ -279,7 +329,7 @@ __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict
 }
 
 // T steps per launch, state in registers between steps
-template <bool LOAD, int BLOCK>
+template <bool LOAD, int BLOCK, int SPEC>
 __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* __restrict__ actions,
                                                    float* __restrict__ obs, float* __restrict__ reward,
                                                    uint8_t* __restrict__ trunc) {
@@ -296,14 +346,14 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
       const float4 action = reinterpret_cast<const float4*>(actions)[(size_t)t * a.n + i];
       float r;
       uint8_t tr;
-      env_step<LOAD>(a, i, e, action, wtile + lane * a.D, &r, &tr);
+      env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &tr);
       reward[(size_t)t * a.n + i] = r;
       trunc[(size_t)t * a.n + i] = tr;
     }
     __builtin_amdgcn_wave_barrier();
     if (wave_base < a.n) {
       const int rows = min(64, a.n - wave_base);
-      flush_obs(wtile, obs + ((size_t)t * a.n + wave_base) * a.D, rows, a.D);
+      flush_obs_any<SPEC>(wtile, obs + ((size_t)t * a.n + wave_base) * a.D, rows, a.D);
     }
     __builtin_amdgcn_wave_barrier();
   }
@@ -325,7 +375,7 @@ __global__ __launch_bounds__(BLOCK) void k_observe(KArgs a, float* __restrict__ 
     float sv[33];
     M3<float> Rq;
     drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
-    write_obs_row<LOAD>(a, e, sv, &Rq, wtile + lane * a.D);
+    write_obs_row<LOAD, SPEC_GENERIC>(a, e, sv, &Rq, wtile + lane * a.D);
   }
   __builtin_amdgcn_wave_barrier();
   if (wave_base < a.n) flush_obs(wtile, obs + (size_t)wave_base * a.D, min(64, a.n - wave_base), a.D);
@@ -566,6 +616,7 @@ struct qd_env {
   ParamCfg pc;
   uint32_t regen;
   int D, ns;
+  int spec;
   bool load;
 };
 
@@ -688,6 +739,15 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   e->pc.random_params = c->random_params;
   e->pc.load = e->load ? 1 : 0;
   e->regen = 0;
+  e->spec = SPEC_GENERIC;
+  if (e->load && c->obs_kind == QD_OBS_RPY_PARAMS && c->reward_kind == QD_REW_DISTANCE_ENERGY && c->ctrl_map == QD_CTRL_AFFINE &&
+      c->term_kind == QD_TERM_DEFAULT)
+    e->spec = SPEC_RMA;
+  else if (e->load && c->obs_kind == QD_OBS_FULLSTATE && c->reward_kind == QD_REW_PEND_EN4 && c->ctrl_map == QD_CTRL_AFFINE &&
+           c->term_kind == QD_TERM_DEFAULT)
+    e->spec = SPEC_LSTM;
+  else if (!e->load && c->obs_kind == QD_OBS_SIMPLE && c->term_kind == QD_TERM_SIMPLE && c->ctrl_map == QD_CTRL_DIRECT)
+    e->spec = SPEC_SIMPLE;
   *out = e;
   return QD_OK;
 }
@@ -807,15 +867,23 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   // one wavefront per workgroup while the batch is small (spreads 64 waves over 64 CUs);
   // 256-thread workgroups once there are enough waves to fill the chip several times over
-  if (k.n >= 65536) {
-    const dim3 grid((k.n + 255) / 256), block(256);
-    if (env->load) QD_LAUNCH((k_step<true, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-    else QD_LAUNCH((k_step<false, 256>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-  } else {
-    const dim3 grid(blocks64(k.n)), block(64);
-    if (env->load) QD_LAUNCH((k_step<true, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-    else QD_LAUNCH((k_step<false, 64>), grid, block, 0, S(stream), k, actions, obs, reward, truncated);
-  }
+#define QD_STEP_LAUNCH(LOADV, BLK, SPECV) \
+  QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3((k.n + BLK - 1) / BLK), dim3(BLK), 0, S(stream), k, actions, obs, reward, truncated)
+#define QD_STEP_BLOCK(BLK)                                                   \
+  do {                                                                       \
+    if (env->load) {                                                         \
+      if (env->spec == SPEC_RMA) QD_STEP_LAUNCH(true, BLK, SPEC_RMA);        \
+      else if (env->spec == SPEC_LSTM) QD_STEP_LAUNCH(true, BLK, SPEC_LSTM); \
+      else QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC);                          \
+    } else {                                                                 \
+      if (env->spec == SPEC_SIMPLE) QD_STEP_LAUNCH(false, BLK, SPEC_SIMPLE); \
+      else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
+    }                                                                        \
+  } while (0)
+  if (k.n >= 65536) QD_STEP_BLOCK(256);
+  else QD_STEP_BLOCK(64);
+#undef QD_STEP_BLOCK
+#undef QD_STEP_LAUNCH
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
@@ -827,8 +895,16 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   if (T == 0) return QD_OK;
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   const dim3 grid(blocks64(k.n)), block(64);
-  if (env->load) QD_LAUNCH((k_rollout<true, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
-  else QD_LAUNCH((k_rollout<false, 64>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated);
+#define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout<LOADV, 64, SPECV>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated)
+  if (env->load) {
+    if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
+    else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
+    else QD_ROLL(true, SPEC_GENERIC);
+  } else {
+    if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
+    else QD_ROLL(false, SPEC_GENERIC);
+  }
+#undef QD_ROLL
   QD_LAUNCH_CHECK();
   return QD_OK;
 }

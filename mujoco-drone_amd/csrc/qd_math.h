@@ -123,22 +123,19 @@ QD_HD void qsincos(float a, float* s, float* c) {
 }
 QD_HD void qsincos(double a, double* s, double* c) { *s = sin(a); *c = cos(a); }
 
-// atan on the whole line (Cephes single-precision scheme: two range reductions + degree-4 kernel in x^2)
-QD_HD float qatan_pos(float x) {  // x >= 0
-  float y0 = 0.f;
-  if (x > 2.414213562373095f) { y0 = 1.5707963267948966f; x = -frcp(x); }
-  else if (x > 0.4142135623730950f) { y0 = 0.7853981633974483f; x = (x - 1.0f) * frcp(x + 1.0f); }
-  const float z = x * x;
-  const float p = fmaf(z, fmaf(z, fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
-  return y0 + fmaf(p * z, x, x);
-}
+// atan2, branch-free (a lane-divergent branch costs more than the handful of selects): reduce to
+// t = min/max in [0,1], one more reduction at tan(pi/8) (Cephes single-precision kernel), then undo.
 QD_HD float qatan2(float y, float x) {
   const float ax = fabsf(x), ay = fabsf(y);
-  float r;
-  if (ax == 0.f && ay == 0.f) r = 0.f;
-  else if (ax >= ay) r = qatan_pos(ay * frcp(ax));
-  else r = 1.5707963267948966f - qatan_pos(ax * frcp(ay));
-  if (x < 0.f) r = 3.14159265358979323846f - r;
+  const float mx = fmaxf(fmaxf(ax, ay), 1e-37f), mn = fminf(ax, ay);
+  const float t = mn * frcp(mx);
+  const bool mid = t > 0.4142135623730950f;
+  const float tt = mid ? (t - 1.0f) * frcp(t + 1.0f) : t;
+  const float z = tt * tt;
+  const float p = fmaf(z, fmaf(z, fmaf(z, 8.05374449538e-2f, -1.38776856032e-1f), 1.99777106478e-1f), -3.33329491539e-1f);
+  float r = (mid ? 0.7853981633974483f : 0.0f) + fmaf(p * z, tt, tt);
+  r = ay > ax ? 1.5707963267948966f - r : r;
+  r = x < 0.f ? 3.14159265358979323846f - r : r;
   return y < 0.f ? -r : r;
 }
 QD_HD double qatan2(double y, double x) { return atan2(y, x); }

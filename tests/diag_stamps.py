@@ -51,3 +51,13 @@ print("slowest wave phases:", one[order[-1]].tolist(), "fastest:", one[order[0]]
 rt0 = rt[:, 0] - rt[:, 0].min(); rt1 = rt[:, 1] - rt[:, 0].min()
 print("start ticks:", rt0.tolist())
 print("end ticks:", rt1.tolist())
+# host-side cost of one step call (enqueue only): issue 3000 steps, time the Python loop, then the drain
+import time
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for i in range(3000):
+    env.vector_step_tensor(a[i % 8])
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print("host enqueue %.2f us/step; total incl. drain %.2f us/step" % ((t1 - t0) / 3000 * 1e6, (t2 - t0) / 3000 * 1e6))
