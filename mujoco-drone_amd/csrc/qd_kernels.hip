@@ -10,6 +10,8 @@
 //   ACC  (accelerometer xyz, -)                 M0..M6 derived model constants (qd_model.h)
 //   P0   (mass, arm_len, motor_force, motor_tau) P1 (pendulum_len, weight_mass, -, -)
 //   REF  (x,y,z,yaw) per-env reference (only read when per_env_reference is set)
+//   NX0..NX4 the pre-sampled initial state of the env's NEXT episode: (pos,th1) (quat) (vel,th2) (angvel,thd1)
+//        (thd2, episode tag:u32, valid:u32, -), see "reset pool" below
 // Observations are produced row-major [N,D] (what the policy network consumes); a
 // wavefront's 64 rows are one contiguous 64*D*4-byte span, so rows are staged through LDS
 // and written back with full-width coalesced stores.
@@ -31,6 +33,7 @@ namespace qd {
 
 enum Group {
   G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_M4, G_M5, G_M6, G_P0, G_P1, G_REF,
+  G_NX0, G_NX1, G_NX2, G_NX3, G_NX4,  // pre-sampled initial state of each env's next episode (filled by sampler waves)
   NUM_GROUPS
 };
 constexpr int RAW_PLANES = 6;
@@ -47,6 +50,8 @@ struct KArgs {
   float max_distance;
   int max_steps, auto_reset, D;
   int obs_needs_acc;  // the observation variant reads the accelerometer entries of the state vector
+  int use_pool;       // auto_reset with random starts: sampler workgroups keep the reset pool filled
+  int main_blocks;    // workgroups [0, main_blocks) step envs; [main_blocks, 2*main_blocks) are samplers
   unsigned long long seed;
   SampleCfg sc;
 };
@@ -142,21 +147,82 @@ __device__ __forceinline__ void refresh_sensor(const KArgs& a, EnvRegs& e) {
   e.flags &= ~FLAG_ACC_STALE;
 }
 
+// the initial state of episode `episode` of env i (positions, attitude, velocities, hinges; NOT the activations)
+template <bool LOAD>
+__device__ __forceinline__ void sample_episode(const KArgs& a, int i, uint32_t episode, State<float>& s) {
+  if (a.sc.random_start == QD_START_SIMPLE) {
+    sample_simple(a.sc, a.seed, (uint32_t)i, (uint32_t)a.n, episode, s);
+  } else {
+    float z[16], u[2];
+    sample_draws(a.seed, (uint32_t)i, episode, z, u);
+    sample_state<LOAD>(a.sc, z, u, s);
+  }
+}
+
 // sample_state for this lane's env, episode counter advanced.  eager_sensor: run mj_forward's sensor
 // part now (reset kernels); otherwise only mark the stored reading stale -- it is recomputed by the
 // next physics step anyway, and by the state/observation getters if they run before that step.
 template <bool LOAD>
 __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e, bool eager_sensor) {
-  if (a.sc.random_start == QD_START_SIMPLE) {
-    sample_simple(a.sc, a.seed, (uint32_t)i, (uint32_t)a.n, e.episode, e.s);
-  } else {
-    float z[16], u[2];
-    sample_draws(a.seed, (uint32_t)i, e.episode, z, u);
-    sample_state<LOAD>(a.sc, z, u, e.s);
-  }
+  sample_episode<LOAD>(a, i, e.episode, e.s);
   e.episode += 1u;
   e.num_steps = 0;
   if (eager_sensor) refresh_sensor<LOAD>(a, e);
+  else e.flags |= FLAG_ACC_STALE;
+}
+
+// ---- reset pool ------------------------------------------------------------------------------
+// Drawing a new initial state costs ~1000 instructions (5 Philox blocks, 8 Box-Muller pairs, the
+// transforms).  Done inline by the lanes that truncate, it sits on the critical path of their
+// wavefront -- and with 4096 envs and ~150-step episodes a third of the 64 wavefronts contain such a
+// lane every step, so the whole launch waits for it.  Instead k_step is launched with TWICE the
+// workgroups: the second half ("sampler" workgroups, on CUs the 64 physics waves leave idle) keeps
+// one pre-sampled initial state per env ready in the NX planes; a truncating lane only loads it.
+// The sample for (env, episode) is a pure function of the Philox counter, so results do not depend
+// on who computes it or when.  Protocol (no intra-launch synchronisation needed):
+//   sampler, launch k  : if NX4.valid == 0 or NX4.tag != AUX.episode -> write sample(AUX.episode), tag, valid = 1
+//   physics, launch k+1: on truncation, if NX4.valid and NX4.tag == episode -> take it, NX4.valid = 0;
+//                        otherwise (pool not refilled yet, explicit reset in between) sample inline.
+// An entry is consumed at the earliest one launch after it was written (kernel boundary = visibility).
+template <bool LOAD>
+__device__ __forceinline__ void pool_fill(const KArgs& a, int i) {
+  float4* g = a.g;
+  const int np = a.npad;
+  const float4 nx4 = g[G_NX4 * np + i];
+  const uint32_t episode = __float_as_uint(g[G_AUX * np + i].z);
+  if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == episode) return;
+  State<float> s;
+  sample_episode<LOAD>(a, i, episode, s);
+  g[G_NX0 * np + i] = make_float4(s.px, s.py, s.pz, s.th1);
+  g[G_NX1 * np + i] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  g[G_NX2 * np + i] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  g[G_NX3 * np + i] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  g[G_NX4 * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(1u), 0.f);
+}
+
+// reset of a truncated lane inside the step kernel: pool entry if it is there, inline sampling otherwise
+template <bool LOAD>
+__device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e) {
+  bool taken = false;
+  if (a.use_pool) {
+    float4* g = a.g;
+    const int np = a.npad;
+    const float4 nx4 = g[G_NX4 * np + i];
+    if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == e.episode) {
+      const float4 p = g[G_NX0 * np + i], q = g[G_NX1 * np + i], v = g[G_NX2 * np + i], w = g[G_NX3 * np + i];
+      e.s.px = p.x; e.s.py = p.y; e.s.pz = p.z; e.s.th1 = p.w;
+      e.s.qw = q.x; e.s.qx = q.y; e.s.qy = q.z; e.s.qz = q.w;
+      e.s.vx = v.x; e.s.vy = v.y; e.s.vz = v.z; e.s.th2 = v.w;
+      e.s.wx = w.x; e.s.wy = w.y; e.s.wz = w.z; e.s.thd1 = w.w;
+      e.s.thd2 = nx4.x;
+      g[G_NX4 * np + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
+      taken = true;
+    }
+  }
+  if (!taken) sample_episode<LOAD>(a, i, e.episode, e.s);
+  e.episode += 1u;
+  e.num_steps = 0;
+  if (a.obs_needs_acc) refresh_sensor<LOAD>(a, e);
   else e.flags |= FLAG_ACC_STALE;
 }
 
@@ -206,20 +272,23 @@ __device__ __forceinline__ void flush_obs(const float* tile, float* dst, int row
   for (int j = (n4 << 2) + lane; j < total; j += 64) dst[j] = tile[j];
 }
 
-// full wavefront, row length known at compile time: all LDS reads are issued before the first store
+// full wavefront, row length known at compile time: all LDS reads are issued before the first store.
+// FULL unpredicated rounds keep v[] in registers (a predicated round made the compiler index it dynamically
+// and park it in scratch); the partial last round is handled on its own.
 template <int D>
 __device__ __forceinline__ void flush_obs_static(const float* tile, float* dst) {
-  constexpr int N4 = 16 * D, IT = (N4 + 63) / 64;
+  constexpr int N4 = 16 * D, FULL = N4 / 64, TAIL = N4 % 64;
   const int lane = threadIdx.x & 63;
-  const float4* t4 = reinterpret_cast<const float4*>(tile);
-  float4* d4 = reinterpret_cast<float4*>(dst);
-  float4 v[IT];
+  const float4* t4 = reinterpret_cast<const float4*>(tile) + lane;
+  float4* d4 = reinterpret_cast<float4*>(dst) + lane;
+  float4 v[FULL > 0 ? FULL : 1];
 #pragma unroll
-  for (int k = 0; k < IT; k++)
-    if (lane + 64 * k < N4) v[k] = t4[lane + 64 * k];
+  for (int k = 0; k < FULL; k++) v[k] = t4[64 * k];
+  float4 vt = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (TAIL > 0 && lane < TAIL) vt = t4[64 * FULL];
 #pragma unroll
-  for (int k = 0; k < IT; k++)
-    if (lane + 64 * k < N4) d4[lane + 64 * k] = v[k];
+  for (int k = 0; k < FULL; k++) d4[64 * k] = v[k];
+  if (TAIL > 0 && lane < TAIL) d4[64 * FULL] = vt;
 }
 template <int SPEC> constexpr int spec_obs_dim() { return SPEC == SPEC_RMA ? 22 : SPEC == SPEC_LSTM ? 23 : SPEC == SPEC_SIMPLE ? 6 : 0; }
 
@@ -275,7 +344,7 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
     r = reward<float>(spec_reward<SPEC>(a), sv, act4, e.num_steps, e.ref, a.max_distance, &Rq);
   }
   if (a.auto_reset && tr) {
-    resample<LOAD>(a, i, e, a.obs_needs_acc != 0);
+    reset_in_step<LOAD>(a, i, e);
     if (term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
   *rew = r;
@@ -289,6 +358,11 @@ template <bool LOAD, int BLOCK, int SPEC>
 __global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
+  if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
+    const int j = ((int)blockIdx.x - a.main_blocks) * BLOCK + threadIdx.x;
+    if (j < a.n) pool_fill<LOAD>(a, j);
+    return;
+  }
   const int i = blockIdx.x * BLOCK + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   float* wtile = tile + wave * OBS_LDS_FLOATS;
@@ -443,6 +517,7 @@ __global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
   if (full) {
     g[G_AUX * np + i] = make_float4(0.f, __int_as_float(0), __uint_as_float(0u), 0.f);
     g[G_REF * np + i] = make_float4(a.ref[0], a.ref[1], a.ref[2], a.ref[3]);
+    g[G_NX4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
   } else {
     float4 aux = g[G_AUX * np + i];
     aux.x = 0.f;
@@ -721,6 +796,10 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.frame_skip = c->frame_skip; k.ctrl_map = c->ctrl_map; k.obs_kind = c->obs_kind; k.reward_kind = c->reward_kind;
   k.term_kind = c->term_kind; k.max_distance = (float)c->max_distance; k.max_steps = c->max_steps;
   k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
+  // sampler workgroups pay off while the launch is a latency chain (few waves, idle CUs); with >= 65536 envs the
+  // chip is full and a second set of workgroups only adds traffic, so truncated lanes sample inline there
+  k.use_pool = (c->auto_reset && c->random_start != QD_START_FIXED && c->num_envs < 65536) ? 1 : 0;
+  k.main_blocks = 0;
   {
     const int ok = c->obs_kind;
     const bool reads_acc_load = ok == QD_OBS_RAW || ok == QD_OBS_FULLSTATE || ok == QD_OBS_FULLSTATE_ZVEC || ok == QD_OBS_PRY_ACC ||
@@ -867,8 +946,13 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   // one wavefront per workgroup while the batch is small (spreads 64 waves over 64 CUs);
   // 256-thread workgroups once there are enough waves to fill the chip several times over
-#define QD_STEP_LAUNCH(LOADV, BLK, SPECV) \
-  QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3((k.n + BLK - 1) / BLK), dim3(BLK), 0, S(stream), k, actions, obs, reward, truncated)
+#define QD_STEP_LAUNCH(LOADV, BLK, SPECV)                                                                         \
+  do {                                                                                                            \
+    KArgs kk = k;                                                                                                 \
+    kk.main_blocks = (k.n + BLK - 1) / BLK;                                                                       \
+    QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3(kk.main_blocks * (k.use_pool ? 2 : 1)), dim3(BLK), 0, S(stream), kk, \
+              actions, obs, reward, truncated);                                                                   \
+  } while (0)
 #define QD_STEP_BLOCK(BLK)                                                   \
   do {                                                                       \
     if (env->load) {                                                         \

@@ -157,9 +157,11 @@ template <class T> QD_HD T qmax(T a, T b) { return a > b ? a : b; }
 template <class T> QD_HD T qmin(T a, T b) { return a < b ? a : b; }
 template <class T> QD_HD T qclamp(T x, T lo, T hi) { return qmin(qmax(x, lo), hi); }
 
-// numpy float remainder: sign follows the divisor (b > 0 here): a - floor(a/b)*b
+// numpy float remainder for a positive constant divisor b (sign follows the divisor): a - floor(a/b)*b.
+// The quotient uses the reciprocal (a multiply instead of the 12-instruction IEEE division); if its rounding
+// lands on the wrong side of an integer the two corrections below bring the result back into [0, b).
 template <class T> QD_HD T npmod(T a, T b) {
-  T m = a - qfloor(a / b) * b;
+  T m = a - qfloor(a * (T(1) / b)) * b;
   if (m < T(0)) m += b;
   if (m >= b) m -= b;
   return m;

@@ -172,9 +172,10 @@ class BaseDroneEnv(_VectorEnvBase):
                                            opt=types.SimpleNamespace(timestep=1.0 / self.frequency))
         _VectorEnvBase.__init__(self, self.observation_space, self.action_space, self.num_drones)
         self.num_envs = self.num_drones
-        self._host_cache = {}
+        self._host_cache = None
         self._obs_host = None
         self._ref_pushed = self._reference
+        self._regen_at = self.regen_env_at_steps if (self.random_params and self.regen_env_at_steps) else 0
         self.num_steps = np.zeros((self.num_drones,), dtype=np.int64)
         qpos, qvel = self._flat_state()[:2]
         self.init_qpos, self.init_qvel = qpos.copy(), qvel.copy()
@@ -234,15 +235,21 @@ class BaseDroneEnv(_VectorEnvBase):
         return self.model.opt.timestep * self.frame_skip
 
     def _invalidate(self):
-        self._host_cache = {}
+        self._host_cache = None
+
+    def _cache(self):
+        if self._host_cache is None:
+            self._host_cache = {}
+        return self._host_cache
 
     def _flat_state(self):
         """(qpos, qvel, act, sensordata) as flat float64 arrays in MuJoCo's order"""
-        if 'flat' not in self._host_cache:
+        c = self._cache()
+        if 'flat' not in c:
             qpos, qvel, act, sens, steps = self._dev.get_state()
-            self._host_cache['flat'] = tuple(x.cpu().numpy().astype(np.float64).ravel() for x in (qpos, qvel, act, sens))
-            self._host_cache['steps'] = steps.cpu().numpy().astype(np.int64)
-        return self._host_cache['flat']
+            c['flat'] = tuple(x.cpu().numpy().astype(np.float64).ravel() for x in (qpos, qvel, act, sens))
+            c['steps'] = steps.cpu().numpy().astype(np.int64)
+        return c['flat']
 
     @property
     def data(self):
@@ -254,17 +261,19 @@ class BaseDroneEnv(_VectorEnvBase):
     def states(self):
         """list of per-drone state vectors (BaseDroneEnv.py:148,273,325).  QUIRK C-1: like the reference,
         the list is refreshed by vector_step / reset_model, NOT by reset_at."""
-        if 'states' not in self._host_cache:
-            self._host_cache['states'] = list(self._dev.drone_states().cpu().numpy().astype(np.float64))
-        return self._host_cache['states']
+        c = self._cache()
+        if 'states' not in c:
+            c['states'] = list(self._dev.drone_states().cpu().numpy().astype(np.float64))
+        return c['states']
 
     @property
     def drone_params(self):
         """list of per-drone parameter dicts (BaseDroneEnv.py:207-216), float64"""
-        if 'params' not in self._host_cache:
+        c = self._cache()
+        if 'params' not in c:
             raw = self._dev.get_params().cpu().numpy()
-            self._host_cache['params'] = [dict(zip(PARAM_NAMES, (float(v) for v in row))) for row in raw]
-        return self._host_cache['params']
+            c['params'] = [dict(zip(PARAM_NAMES, (float(v) for v in row))) for row in raw]
+        return c['params']
 
     def model_constants(self):
         return {k: v.cpu().numpy() for k, v in self._dev.model_constants().items()}
@@ -284,7 +293,7 @@ class BaseDroneEnv(_VectorEnvBase):
         return None
 
     def get_drone_states(self):
-        self._host_cache.pop('states', None)
+        self._cache().pop('states', None)
         return self.states
 
     def _get_obs(self):
@@ -298,7 +307,7 @@ class BaseDroneEnv(_VectorEnvBase):
         qpos, qvel = np.asarray(qpos, dtype=np.float64), np.asarray(qvel, dtype=np.float64)
         assert qpos.shape == (self.model.nq,) and qvel.shape == (self.model.nv,)
         self._dev.set_state(qpos.reshape(self.num_drones, -1), qvel.reshape(self.num_drones, -1))
-        self._host_cache.pop('flat', None)
+        self._cache().pop('flat', None)
 
     def reset_model(self, regen=False):
         """BaseDroneEnv.py:296-326"""
@@ -330,9 +339,9 @@ class BaseDroneEnv(_VectorEnvBase):
         assert index < self.num_drones
         self._dev.reset_at(index)
         self.num_steps[index] = 0
-        self._host_cache.pop('flat', None)
+        self._cache().pop('flat', None)
         if self.fresh_reset_obs:
-            self._host_cache.pop('states', None)
+            self._cache().pop('states', None)
             self._obs_host = None
         ob = self._get_obs()[index]
         return ob, {}
@@ -377,12 +386,13 @@ class BaseDroneEnv(_VectorEnvBase):
         until the next step.  The regen rule of vector_step is applied."""
         if self._reference is not self._ref_pushed:
             self._push_reference()
-        o, r, t = out if out is not None else (None, None, None)
-        obs, rew, trunc = self._dev.step(actions, o, r, t)
+        if out is None:
+            obs, rew, trunc = self._dev.step(actions)
+        else:
+            obs, rew, trunc = self._dev.step(actions, out[0], out[1], out[2])
         self.total_steps += 1
-        self._host_cache = {}
-        self._obs_host = None
-        if self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps:
+        self._host_cache = self._obs_host = None
+        if self._regen_at and self.total_steps == self._regen_at:
             self.total_steps = 0
             self._dev.randomize_params()
             self._dev.reset(None, want_obs=False)

@@ -44,6 +44,7 @@ class DeviceEnv:
         L.check(self.lib.qd_create(C.byref(cfg), _ptr(self.arena), nbytes, C.byref(handle)))
         self.handle = handle
         self._qd_step = self.lib.qd_step
+        self._obs_ptr, self._rew_ptr, self._trunc_ptr = self.obs.data_ptr(), self.reward.data_ptr(), self.truncated.data_ptr()
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         L.check(self.lib.qd_init(self.handle, self._stream()))
 
@@ -120,13 +121,16 @@ class DeviceEnv:
     def step(self, actions, obs=None, reward=None, truncated=None):
         """actions: float32 device tensor with 4*N values (anything else raises ValueError like the reference).
         Hot path: one ctypes call -> one kernel launch on torch's current stream, no allocation, no sync."""
-        if (type(actions) is not torch.Tensor or actions.dtype is not torch.float32 or actions.device != self.device
-                or not actions.is_contiguous()):
+        if not (type(actions) is torch.Tensor and actions.dtype is torch.float32 and actions.is_cuda
+                and actions.is_contiguous()) or actions.device != self.device:
             actions = torch.as_tensor(np.asarray(actions, dtype=np.float32) if not isinstance(actions, torch.Tensor)
                                       else actions).to(device=self.device, dtype=torch.float32).contiguous()
-        obs = self.obs if obs is None else obs
-        reward = self.reward if reward is None else reward
-        truncated = self.truncated if truncated is None else truncated
+        if obs is None:
+            rc = self._qd_step(self.handle, actions.data_ptr(), actions.numel(), self._obs_ptr, self._rew_ptr,
+                               self._trunc_ptr, _raw_stream(self._dev_index))
+            if rc:
+                L.check(rc)
+            return self.obs, self.reward, self.truncated
         rc = self._qd_step(self.handle, actions.data_ptr(), actions.numel(), obs.data_ptr(), reward.data_ptr(),
                            truncated.data_ptr(), _raw_stream(self._dev_index))
         if rc:
@@ -160,7 +164,7 @@ class DeviceEnv:
     def model_constants(self):
         """per-env derived model constants (qd_model.h), read straight from the arena planes"""
         npad = (self.n + 255) // 256 * 256
-        ngroups, first = 17, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
+        ngroups, first = 22, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
         g = self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
         names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "klin0", "kang0", "qlx0",
                  "qly0", "qlz0", "qax0", "qay0", "qaz0", "m2", "lc", "I2t", "I2a", "klin2", "kang2", "qlt2", "qla2",
