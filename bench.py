@@ -24,6 +24,13 @@ if ROOT not in sys.path:
 
 ALG_BYTES = {"load22": 309, "noload6": 181, "load23": 329}  # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+WORKLOADS = {
+    "config3": "BASELINE config 3: drone + hanging load, domain-randomised params, LocalFrameRPYParamsEnv obs (D=22), "
+               "distance_energy_reward, max_steps=1024, regen every 1024 steps, in-kernel auto-reset",
+    "config2": "BASELINE config 2: SimpleDrone (no load), fixed init, U[0.5,1) rotor actions, 2 substeps at 1 kHz",
+    "config5": "BASELINE config 5: drone + load, LocalFrameFullStateEnv obs (D=23), distance_energy_reward_pendulum_en4, "
+               "state_difficulty 0.8, per-env moving circle waypoint (r=1, f=0.5 Hz) generated in the step kernel",
+}
 
 
 def make_env(kind, n, seed, device, auto_reset=True):
@@ -35,6 +42,12 @@ def make_env(kind, n, seed, device, auto_reset=True):
                    regen_env_at_steps=1024, reward_fcn=rewards.distance_energy_reward, seed=seed, device=device,
                    auto_reset=auto_reset)
         return ow.LocalFrameRPYParamsEnv(cfg), "load22"
+    if kind == "config5":
+        cfg = dict(base_config)
+        cfg.update(num_drones=n, random_params=False, state_difficulty=0.8, max_steps=1024, seed=seed, device=device,
+                   reward_fcn=rewards.distance_energy_reward_pendulum_en4, auto_reset=auto_reset,
+                   reference_trajectory={"type": "circle", "radius": 1.0, "frequency": 0.5})
+        return ow.LocalFrameFullStateEnv(cfg), "load23"
     if kind == "config2":
         from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
         from mujoco_drone_amd import _lib as L
@@ -129,7 +142,7 @@ def main():
     ap.add_argument("--steps", type=int, default=8192)
     ap.add_argument("--warmup", type=int, default=512)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
-    ap.add_argument("--config", default="config3", choices=["config3", "config2"])
+    ap.add_argument("--config", default="config3", choices=["config3", "config2", "config5"])
     ap.add_argument("--fragment", type=int, default=1024, help="steps per all-gathered trajectory fragment (N>1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
@@ -147,14 +160,14 @@ def main():
     n, K, W = args.envs, args.steps, args.warmup
 
     env, alg = make_env(args.config, n, par.shard_seed(42, rank), device)
-    step = env.vector_step_tensor if args.config == "config3" else env.step_tensor
-    if args.config == "config3":
+    step = env.vector_step_tensor if args.config != "config2" else env.step_tensor
+    if args.config != "config2":
         env.vector_reset_tensor()
         D = env._dev.D
     else:
         env.reset()
         D = 6
-    lo, hi = (0.0, 1.0) if args.config == "config3" else (0.5, 1.0)
+    lo, hi = (0.0, 1.0) if args.config != "config2" else (0.5, 1.0)
     P = 64
     g = torch.Generator(device=device); g.manual_seed(1000 + rank)
     actions = lo + (hi - lo) * torch.rand((P, n, 4), generator=g, device=device, dtype=torch.float32)
@@ -203,13 +216,9 @@ def main():
         out = {"metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
                "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": ("BASELINE config 3: drone + hanging load, domain-randomised params, "
-                                       "LocalFrameRPYParamsEnv obs (D=22), distance_energy_reward, max_steps=1024, regen every "
-                                       "1024 steps, in-kernel auto-reset" if args.config == "config3" else
-                                       "BASELINE config 2: SimpleDrone (no load), fixed init, U[0.5,1) rotor actions, "
-                                       "2 substeps at 1 kHz") + ("; per-fragment RCCL all-gather of [T=%d,N,...] trajectories" % T
-                                                                if world > 1 else ""),
-                          "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 1 if args.config == "config3" else 2,
+               "config": {"workload": WORKLOADS[args.config] + ("; per-fragment RCCL all-gather of [T=%d,N,...] trajectories" % T
+                                                                 if world > 1 else ""),
+                          "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 2 if args.config == "config2" else 1,
                           "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
         # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
@@ -240,7 +249,7 @@ def main():
                 sweep = []
                 for nn in (4096, 65536, 1048576):
                     e2, alg2 = make_env(args.config, nn, 7, device)
-                    (e2.vector_reset_tensor() if args.config == "config3" else e2.reset())
+                    (e2.vector_reset_tensor() if args.config != "config2" else e2.reset())
                     a2 = lo + (hi - lo) * torch.rand((4, nn, 4), device=device, dtype=torch.float32)
                     for _ in range(20):
                         e2._dev.step(a2[0])
@@ -253,7 +262,7 @@ def main():
                 extras["env_count_sweep"] = sweep
                 # multi-step kernel (state in registers across T steps)
                 e3, _ = make_env(args.config, n, 11, device)
-                if args.config == "config3":
+                if args.config != "config2":
                     e3.vector_reset_tensor()
                     a3 = torch.rand((256, n, 4), device=device, dtype=torch.float32)
                     e3._dev.rollout(a3)
@@ -263,7 +272,7 @@ def main():
                         e3._dev.rollout(a3)
                     torch.cuda.synchronize()
                     extras["rollout_kernel_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
-                other = "config2" if args.config == "config3" else "config3"
+                other = "config2" if args.config != "config2" else "config3"
                 e4, alg4 = make_env(other, n, 5, device)
                 (e4.vector_reset_tensor() if other == "config3" else e4.reset())
                 lo4, hi4 = (0.0, 1.0) if other == "config3" else (0.5, 1.0)

@@ -54,6 +54,8 @@ enum { QD_START_FIXED = 0,  /* random_start_pos = False   (BaseDroneEnv.py:245-2
        QD_START_RANDOM = 1, /* random_start_pos = True    (BaseDroneEnv.py:220-244) */
        QD_START_SIMPLE = 2  /* SimpleDrone.reset_model    (SimpleDrone.py:63-72)    */ };
 
+enum { QD_REF_STATIC = 0, QD_REF_CIRCLE = 1 };
+
 /* observation variants: BaseDroneEnv._get_obs and the classes of observation_wrappers.py, in file order */
 enum {
   QD_OBS_RAW = 0, QD_OBS_GLOBAL_RPY, QD_OBS_LOCAL_PRY, QD_OBS_FULLSTATE, QD_OBS_FULLSTATE_ZVEC, QD_OBS_PRY_ACC,
@@ -93,6 +95,13 @@ typedef struct qd_config {
   double   param_center[6], param_width[6]; /* mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass */
   double   param_difficulty;
   uint64_t seed;
+  /* extension (BASELINE config 5): moving waypoint computed inside the step kernel.
+   * QD_REF_CIRCLE: gen_circle_trajectory (evaluation.py:135-138) around `reference`, phase-shifted per env:
+   *   ref_i(k) = reference + (r cos(2 pi f k dt + 2 pi i/N), r sin(...), 0, 0),  k = the env's episode step,
+   *   dt = frame_skip * timestep; the step taken from episode step k is rewarded against ref_i(k). */
+  int32_t  ref_mode;            /* QD_REF_STATIC / QD_REF_CIRCLE */
+  int32_t  reserved0;
+  double   ref_radius, ref_frequency;
 } qd_config;
 
 const char* qd_last_error(void);

@@ -52,6 +52,8 @@ struct KArgs {
   int obs_needs_acc;  // the observation variant reads the accelerometer entries of the state vector
   int use_pool;       // auto_reset with random starts: sampler workgroups keep the reset pool filled
   int main_blocks;    // workgroups [0, main_blocks) step envs; [main_blocks, 2*main_blocks) are samplers
+  int ref_mode;       // QD_REF_CIRCLE: the reference is a function of (env, episode step), see moving_reference()
+  float ref_radius, ref_omega_dt, ref_phase_step;  // radius, 2 pi f dt, 2 pi / N
   unsigned long long seed;
   SampleCfg sc;
 };
@@ -91,6 +93,16 @@ template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
   return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : SPEC == SPEC_GENERIC ? a.ctrl_map : (int)QD_CTRL_AFFINE;
 }
 
+// gen_circle_trajectory (evaluation.py:135-138) around the configured reference, one phase per env
+__device__ __forceinline__ void moving_reference(const KArgs& a, int i, int k, float ref[4]) {
+  float sn, cs;
+  qsincos(a.ref_omega_dt * (float)k + a.ref_phase_step * (float)i, &sn, &cs);
+  ref[0] = a.ref[0] + a.ref_radius * cs;
+  ref[1] = a.ref[1] + a.ref_radius * sn;
+  ref[2] = a.ref[2];
+  ref[3] = a.ref[3];
+}
+
 template <bool LOAD>
 __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   const float4* g = a.g;
@@ -119,7 +131,9 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
     e.M.qla2 = m6.x; e.M.qat2 = m6.y; e.M.qaa2 = m6.z;
   }
   e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
-  if (a.per_env_ref) {
+  if (a.ref_mode == QD_REF_CIRCLE) {
+    moving_reference(a, i, e.num_steps, e.ref);
+  } else if (a.per_env_ref) {
     const float4 r = g[G_REF * np + i];
     e.ref[0] = r.x; e.ref[1] = r.y; e.ref[2] = r.z; e.ref[3] = r.w;
   } else {
@@ -345,6 +359,7 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   }
   if (a.auto_reset && tr) {
     reset_in_step<LOAD>(a, i, e);
+    if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, 0, e.ref);
     if (term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
   *rew = r;
@@ -418,6 +433,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
   for (int t = 0; t < T; t++) {
     if (live) {
       const float4 action = reinterpret_cast<const float4*>(actions)[(size_t)t * a.n + i];
+      if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, e.num_steps, e.ref);
       float r;
       uint8_t tr;
       env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &tr);
@@ -798,6 +814,11 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
   // sampler workgroups pay off while the launch is a latency chain (few waves, idle CUs); with >= 65536 envs the
   // chip is full and a second set of workgroups only adds traffic, so truncated lanes sample inline there
+  if (c->ref_mode != QD_REF_STATIC && c->ref_mode != QD_REF_CIRCLE) { delete e; return fail(QD_ERR_INVALID, "unknown ref_mode %d", c->ref_mode); }
+  k.ref_mode = c->ref_mode;
+  k.ref_radius = (float)c->ref_radius;
+  k.ref_omega_dt = (float)(6.283185307179586 * c->ref_frequency * c->timestep * c->frame_skip);
+  k.ref_phase_step = (float)(6.283185307179586 / c->num_envs);
   k.use_pool = (c->auto_reset && c->random_start != QD_START_FIXED && c->num_envs < 65536) ? 1 : 0;
   k.main_blocks = 0;
   {

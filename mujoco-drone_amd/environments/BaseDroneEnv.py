@@ -152,6 +152,9 @@ class BaseDroneEnv(_VectorEnvBase):
         self.auto_reset = bool(config.get('auto_reset', False))
         self.per_env_reference = bool(config.get('per_env_reference', False))
         self.fresh_reset_obs = bool(config.get('fresh_reset_obs', False))  # False = reference behaviour (C-1)
+        # moving waypoint inside the step kernel: {'type': 'circle', 'radius': r, 'frequency': f} around `reference`,
+        # one phase per env (gen_circle_trajectory, evaluation.py:135-138); None = static reference
+        self.reference_trajectory = config.get('reference_trajectory', None)
 
         if getattr(self.terminated_fcn, '__name__', None) != 'default_termination_fcn':
             raise TypeError("terminated_fcn must be default_termination_fcn: the device step implements the "
@@ -214,6 +217,12 @@ class BaseDroneEnv(_VectorEnvBase):
         c.param_width[:] = [float(iv[1]) for iv in ivs]
         c.param_difficulty = float(self.param_difficulty)
         c.seed = self.seed_value & 0xFFFFFFFFFFFFFFFF
+        if self.reference_trajectory:
+            if self.reference_trajectory.get('type') != 'circle':
+                raise ValueError("reference_trajectory type must be 'circle'")
+            c.ref_mode = L.REF_CIRCLE
+            c.ref_radius = float(self.reference_trajectory.get('radius', 1.0))
+            c.ref_frequency = float(self.reference_trajectory.get('frequency', 0.5))
         return c
 
     # ----------------------------------------------------------------------- attributes

@@ -483,3 +483,37 @@ def test_simple_drone_surface(qd, orc):
     assert abs(rew - (0.1 - np.linalg.norm(qpos[:3] - [0, 0, 1]))) < 1e-5 and term is False and info == {}
     with pytest.raises(ValueError, match="Action dimension mismatch"):
         env.step(np.ones(3))
+
+
+def test_moving_waypoint_circle_config5(qd, orc):
+    """BASELINE config 5: per-env moving reference (gen_circle_trajectory, evaluation.py:135-138, phase-shifted per
+    env) computed inside the step kernel; LocalFrameFullStateEnv + distance_energy_reward_pendulum_en4."""
+    rng = np.random.default_rng(31)
+    n, L, steps = 64, qd._lib, 25
+    obs, rew = "LocalFrameFullStateEnv", "distance_energy_reward_pendulum_en4"
+    c = make_cfg(L, n, load=True, obs=obs, reward=rew, ref=(0.5, -0.5, 15.0, 0.3), max_steps=10 ** 6, max_distance=1e9)
+    c.ref_mode, c.ref_radius, c.ref_frequency = L.REF_CIRCLE, 1.0, 0.5
+    env = qd.dev.DeviceEnv(c)
+    raw = np.tile(CENTER, (n, 1))
+    qpos, qvel, act = rand_state(rng, n, True)
+    env.set_params(raw)
+    env.set_state(qpos, qvel, act)
+    models = [orc.build_model(raw[i]) for i in range(n)]
+    oq, ov, oa = qpos.astype(np.float32).astype(np.float64), qvel.astype(np.float32).astype(np.float64), act.astype(np.float32).astype(np.float64)
+    ok, rk = L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(rew)
+    for k in range(steps):
+        a = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+        o, r, tr = env.step(a)
+        o, r = o.cpu().numpy(), r.cpu().numpy()
+        for i in range(n):
+            ph = 2 * np.pi * 0.5 * k * 0.01 + 2 * np.pi * i / n
+            ref = np.array([0.5 + np.cos(ph), -0.5 + np.sin(ph), 15.0, 0.3])
+            q, v, aa, sens = orc.step(models[i], 0.01, 1, oq[i], ov[i], oa[i], 0.1 + 0.9 * a[i].astype(np.float64))
+            oq[i], ov[i], oa[i] = q, v, aa
+            s = orc.drone_state(1, q, v, sens, aa, ref, raw[i])
+            np.testing.assert_allclose(o[i], orc.obs(ok, s, ref), rtol=2e-4, atol=3e-3)
+            assert abs(r[i] - orc.reward(rk, s, a[i], k + 1, ref, 1e9)) < 2e-3 * max(1.0, abs(r[i]))
+    st = env.drone_states().cpu().numpy()            # reference entries of the state vector follow the waypoint too
+    ph = 2 * np.pi * 0.5 * steps * 0.01 + 2 * np.pi * np.arange(n) / n
+    np.testing.assert_allclose(st[:, 23], 0.5 + np.cos(ph), atol=1e-5)
+    np.testing.assert_allclose(st[:, 24], -0.5 + np.sin(ph), atol=1e-5)
