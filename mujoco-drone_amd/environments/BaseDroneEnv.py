@@ -19,6 +19,7 @@ Differences a user can observe (all listed in DESIGN.md):
 import types
 
 import numpy as np
+import torch
 
 from .. import _lib as L
 from . import rewards as _rewards
@@ -177,6 +178,7 @@ class BaseDroneEnv(_VectorEnvBase):
         self.num_envs = self.num_drones
         self._host_cache = None
         self._obs_host = None
+        self._hb = None
         self._ref_pushed = self._reference
         self._regen_at = self.regen_env_at_steps if (self.random_params and self.regen_env_at_steps) else 0
         self.num_steps = np.zeros((self.num_drones,), dtype=np.int64)
@@ -359,26 +361,51 @@ class BaseDroneEnv(_VectorEnvBase):
         """BaseDroneEnv.py:259-294: list/array of N 4-vectors in [0,1] ->
         (obs list, rewards list, dones list, truncated list | ndarray, infos list)"""
         self._push_reference()
+        n = self.num_drones
         acts = np.asarray(actions, dtype=np.float32)
-        if acts.size != 4 * self.num_drones:
+        if acts.size != 4 * n:
             raise ValueError("Action dimension mismatch")
-        obs, rew, trunc = self._dev.step(acts)
+        hb = self._host_buffers()
+        np.copyto(hb['act_np'], acts.reshape(n, 4))
+        hb['act_dev'].copy_(hb['act_pin'], non_blocking=True)          # pinned H2D on the launch stream
+        obs, rew, trunc = self._dev.step(hb['act_dev'])
         self.num_steps = self.num_steps + 1
         self.total_steps += 1
         self._invalidate()
-        rewards = rew.cpu().numpy().astype(np.float64).tolist()
-        truncated = trunc.cpu().numpy().astype(bool).tolist()
-        dones = [False] * self.num_drones
-        infos = [{} for _ in range(self.num_drones)]
-        if self.auto_reset:
-            self.num_steps = np.where(np.asarray(truncated), 0, self.num_steps)
-        if self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps:
+        regen = self.random_params and self.regen_env_at_steps and self.total_steps == self.regen_env_at_steps
+        hb['rew_pin'].copy_(rew, non_blocking=True)
+        hb['trunc_pin'].copy_(trunc, non_blocking=True)
+        if regen:
             self.total_steps = 0
-            self.reset_model(regen=True)
-            truncated = np.ones(self.num_drones, dtype=bool)  # QUIRK C-5: becomes an ndarray
-            return list(self._obs_host), rewards, dones, truncated, infos
-        self._obs_host = obs.cpu().numpy().astype(np.float64)
+            self._dev.randomize_params()
+            self._dev.reset(None, want_obs=True)
+            self.num_steps = np.zeros((n,), dtype=np.int64)
+        hb['obs_pin'].copy_(self._dev.obs, non_blocking=True)
+        torch.cuda.current_stream(self._dev.device).synchronize()      # the one host sync of the list API
+        rewards = hb['rew_np'].astype(np.float64).tolist()
+        dones = [False] * n
+        infos = [{} for _ in range(n)]
+        self._obs_host = hb['obs_np'].astype(np.float64)
+        if regen:
+            truncated = np.ones(n, dtype=bool)  # QUIRK C-5: becomes an ndarray
+        else:
+            truncated = hb['trunc_np'].astype(bool).tolist()
+            if self.auto_reset:
+                self.num_steps = np.where(hb['trunc_np'] != 0, 0, self.num_steps)
         return list(self._obs_host), rewards, dones, truncated, infos
+
+    def _host_buffers(self):
+        """pinned staging buffers of the list-returning API (allocated on first use)"""
+        if self._hb is None:
+            n, D, dev = self.num_drones, self._dev.D, self._dev.device
+            pin = lambda shape, dt: torch.empty(shape, dtype=dt).pin_memory()
+            hb = {'act_pin': pin((n, 4), torch.float32), 'obs_pin': pin((n, D), torch.float32),
+                  'rew_pin': pin((n,), torch.float32), 'trunc_pin': pin((n,), torch.uint8),
+                  'act_dev': torch.empty((n, 4), dtype=torch.float32, device=dev)}
+            for k in ('act', 'obs', 'rew', 'trunc'):
+                hb[k + '_np'] = hb[k + '_pin'].numpy()
+            self._hb = hb
+        return self._hb
 
     # ----------------------------------------------------------------- tensor fast path
     def vector_reset_tensor(self):

@@ -517,3 +517,40 @@ def test_moving_waypoint_circle_config5(qd, orc):
     ph = 2 * np.pi * 0.5 * steps * 0.01 + 2 * np.pi * np.arange(n) / n
     np.testing.assert_allclose(st[:, 23], 0.5 + np.cos(ph), atol=1e-5)
     np.testing.assert_allclose(st[:, 24], -0.5 + np.sin(ph), atol=1e-5)
+
+
+def test_closed_loop_hover_1200_steps(qd, orc):
+    """Long-horizon CLOSED-LOOP parity (the shape of attitude_test.py: 1200 steps under a cascaded controller): the GPU env
+    and the float64 oracle each run their own loop -- the controller reads each system's own state vector -- from the same
+    randomised initial states and parameters.  Both must settle at the reference and agree all the way."""
+    import sys, os
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from hover_controller import hover_actions
+    rng = np.random.default_rng(77)
+    n, L, steps = 64, qd._lib, 1200
+    ref = (0.0, 0.0, 15.0, 0.3)
+    raw = rand_raw(rng, n, True)
+    qpos = np.zeros((n, 9)); qpos[:, :3] = np.array([0, 0, 15]) + rng.normal(scale=0.4, size=(n, 3)); qpos[:, 3] = 1
+    qpos[:, 7:] = rng.normal(scale=0.2, size=(n, 2))
+    qvel = rng.normal(scale=0.3, size=(n, 8))
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs="BaseDroneEnv", reward="distance_energy_reward", ref=ref, max_steps=10 ** 6))
+    env.set_params(raw)
+    env.set_state(qpos, qvel, np.zeros((n, 4)))
+    ob = orc.Batch(raw, True, 0, L.REWARD_KINDS.index("distance_energy_reward"), 0.01, 1, 1, ref, 4.0, 10 ** 6)
+    ob.qpos[:], ob.qvel[:] = qpos.astype(np.float32), qvel.astype(np.float32)
+    sg = env.drone_states().cpu().numpy().astype(np.float64)
+    so = np.array([orc.drone_state(1, ob.qpos[i], ob.qvel[i], ob.sensor[i], ob.act[i], ref, raw[i]) for i in range(n)])
+    so[:, 16:19] = sg[:, 16:19]  # accelerometer of the initial mj_forward
+    worst = 0.0
+    for t in range(steps):
+        og, rg, tg = env.step(hover_actions(sg, ref).astype(np.float32))
+        oo, ro, to = ob.step(hover_actions(so, ref).astype(np.float32).astype(np.float64), threads=8)
+        sg, so = og.cpu().numpy().astype(np.float64), oo.copy()
+        assert int(tg.sum()) == 0 and int(to.sum()) == 0
+        if t % 100 == 99:
+            err = np.max(np.abs(sg[:, :16] - so[:, :16]) / np.maximum(1.0, np.abs(so[:, :16])))
+            worst = max(worst, float(err))
+    print("closed-loop worst relative state error", worst)
+    assert worst < 1e-4
+    assert np.abs(sg[:, :3] - np.array(ref[:3])).max() < 0.02 and np.abs(sg[:, 12:14]).max() < 0.02   # settled at the reference
+    np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=1e-4)
