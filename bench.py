@@ -155,6 +155,8 @@ def main():
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs a GPU"
+    if os.environ.get("QD_SINGLE_DEVICE"):   # rehearsal of the N>1 path on a one-GPU box (with QD_DIST_BACKEND=gloo)
+        local = 0
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     n, K, W = args.envs, args.steps, args.warmup
@@ -173,24 +175,46 @@ def main():
     actions = lo + (hi - lo) * torch.rand((P, n, 4), generator=g, device=device, dtype=torch.float32)
 
     T = min(args.fragment, K)
-    frag = gather = None
+    frags = gathers = None
+    pending = [None, None]
     if world > 1:
-        frag = par.FragmentBuffers(T, n, D, device)
-        gather = par.FragmentGather(frag, world)
+        # two trajectory fragments in flight: while fragment f is being all-gathered (RCCL, asynchronously, on its
+        # own stream), the envs already write fragment f+1.  The synthetic actions live in the fragment's action
+        # tensor itself -- where a policy would write them -- so no per-step copy is needed.
+        frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
+        gathers = [par.FragmentGather(f, world) for f in frags]
+        for f in frags:
+            f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
+    state = {"cur": 0, "gathers": 0}
 
     def run(k_steps, base=0):
         for t in range(k_steps):
-            a = actions[(base + t) % P]
-            if frag is None:
-                step(a)
-            else:
-                tt = (base + t) % T
-                frag.actions[tt].copy_(a)
-                step(a, out=(frag.obs[tt], frag.rewards[tt], frag.truncated[tt]))
-                if tt == T - 1:
-                    gather(frag)
+            if frags is None:
+                step(actions[(base + t) % P])
+                continue
+            tt = (base + t) % T
+            cur = state["cur"]
+            if tt == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
+                for w in pending[cur]:
+                    w.wait()
+                pending[cur] = None
+            f = frags[cur]
+            step(f.actions[tt], out=(f.obs[tt], f.rewards[tt], f.truncated[tt]))
+            if tt == T - 1:
+                pending[cur] = gathers[cur](f, async_op=True)[1]
+                state["cur"] = cur ^ 1
+                state["gathers"] += 1
+
+    def drain():
+        for b in range(2):
+            if pending[b] is not None:
+                for w in pending[b]:
+                    w.wait()
+                pending[b] = None
 
     run(W)
+    drain()
+    state["gathers"] = 0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -199,6 +223,7 @@ def main():
     t0 = time.perf_counter()
     ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
     run(K, base=W)
+    drain()
     ev1.record()
     torch.cuda.synchronize()
     if world > 1:
@@ -210,6 +235,20 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
+    step_only = None
+    if world > 1:
+        # the same stepping without the trajectory all-gather (reported separately): not part of `value`
+        ks = min(K, 2048)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for t in range(ks):
+            f = frags[0]
+            step(f.actions[t % T], out=(f.obs[t % T], f.rewards[t % T], f.truncated[t % T]))
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
+        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
+        step_only = world * n * ks / float(ts.item())
+
     out = None
     if rank == 0:
         value = world * n * K / dt
@@ -219,7 +258,10 @@ def main():
                "config": {"workload": WORKLOADS[args.config] + ("; per-fragment RCCL all-gather of [T=%d,N,...] trajectories" % T
                                                                  if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world}}
+                          "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world,
+                          "fragment_all_gathers_in_timed_region": state["gathers"],
+                          "all_gather_bytes_per_rank_per_fragment": (frags[0].nbytes() if frags else 0),
+                          "env_steps_per_sec_without_all_gather": step_only}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
         # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
         # back-to-back launches (the regen launches every 1024 steps are < 0.1 % of it), so elapsed / K is the

@@ -432,9 +432,13 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
   const bool live = i < a.n;
   EnvRegs e;
   if (live) load_env<LOAD>(a, i, e);
+  float4 next_action = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live && T > 0) next_action = reinterpret_cast<const float4*>(actions)[i];
   for (int t = 0; t < T; t++) {
     if (live) {
-      const float4 action = reinterpret_cast<const float4*>(actions)[(size_t)t * a.n + i];
+      const float4 action = next_action;
+      // software pipelining: the next step's action is in flight while this step computes
+      if (t + 1 < T) next_action = reinterpret_cast<const float4*>(actions)[(size_t)(t + 1) * a.n + i];
       if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, e.num_steps, e.ref);
       float r;
       uint8_t tr;
