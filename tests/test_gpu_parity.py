@@ -554,3 +554,55 @@ def test_closed_loop_hover_1200_steps(qd, orc):
     assert worst < 1e-4
     assert np.abs(sg[:, :3] - np.array(ref[:3])).max() < 0.02 and np.abs(sg[:, 12:14]).max() < 0.02   # settled at the reference
     np.testing.assert_allclose(rg.cpu().numpy(), ro, atol=1e-4)
+
+
+def test_config3_full_size_4096_envs_200_steps(qd, orc):
+    """BASELINE config 3 at its full size: 4096 envs, domain-randomised parameters (device Philox), random initial states
+    (device reset), 200 steps of U[0,1) rotor actions; every env against the float64 oracle.  Truncation is disabled
+    (max_distance huge) so that all 4096 trajectories run the full 200 steps."""
+    rng = np.random.default_rng(123)
+    n, L, steps = 4096, qd._lib, 200
+    c = make_cfg(L, n, load=True, start=1, random_params=1, seed=42, difficulty=1.0, sdiff=0.2, max_steps=10 ** 6, max_distance=1e9)
+    env = qd.dev.DeviceEnv(c)
+    env.reset()
+    raw = env.get_params().cpu().numpy()
+    q0, v0, a0, _, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    ob = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameRPYParamsEnv"), L.REWARD_KINDS.index("distance_energy_reward"),
+                   0.01, 1, 1, (0, 0, 15, 0), 1e9, 10 ** 6)
+    ob.qpos[:], ob.qvel[:], ob.act[:] = q0, v0, a0
+    acts = rng.uniform(0, 1, (steps, n, 4)).astype(np.float32)
+    for t in range(steps):
+        o, r, tr = env.step(acts[t])
+        oo, orr, otr = ob.step(acts[t].astype(np.float64), threads=8)
+    gq, gv, ga, _, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(gk == steps)
+    err = max(float(np.max(np.abs(g - w) / np.maximum(1.0, np.abs(w)))) for g, w in ((gq, ob.qpos), (gv, ob.qvel), (ga, ob.act)))
+    per_env = np.max(np.abs(gv - ob.qvel) / np.maximum(1.0, np.abs(ob.qvel)), axis=1)
+    print("config 3, 4096 envs, 200 steps: max relative state divergence %.3e (median env %.3e, 99th pct %.3e)"
+          % (err, np.median(per_env), np.percentile(per_env, 99)))
+    assert err < 1e-4
+    np.testing.assert_allclose(o.cpu().numpy(), oo, rtol=2e-4, atol=2e-3)
+    np.testing.assert_allclose(r.cpu().numpy(), orr, rtol=2e-4, atol=2e-3)
+
+
+def test_determinism_and_long_run_stability(qd):
+    """same seed -> bit-identical runs; 3000 auto-resetting steps at 4096 envs stay finite and consistent"""
+    L, n = qd._lib, 4096
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, random_params=1, auto_reset=1, seed=9, max_steps=256, sdiff=0.2))
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    acts = torch.rand((32, n, 4), generator=g, device="cuda")
+    ntr = 0
+    for t in range(3000):
+        oa, ra, ta = a.step(acts[t % 32])
+        if t < 300:
+            ob_, rb, tb = b.step(acts[t % 32])
+            assert torch.equal(oa, ob_) and torch.equal(ra, rb) and torch.equal(ta, tb)
+        ntr += int(ta.sum())
+        if t % 500 == 499:
+            assert torch.isfinite(oa).all() and torch.isfinite(ra).all()
+    q, v, act, s, k = a.get_state()
+    assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(s).all()
+    assert int(k.max()) < 256 and ntr >= 3000 * n // 256          # every env truncates at least every 256 steps
+    assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(n, device=q.device), atol=1e-5)
