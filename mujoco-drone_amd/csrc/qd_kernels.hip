@@ -89,6 +89,9 @@ template <int SPEC> __device__ __forceinline__ int spec_reward(const KArgs& a) {
 template <int SPEC> __device__ __forceinline__ int spec_term(const KArgs& a) {
   return SPEC == SPEC_SIMPLE ? (int)QD_TERM_SIMPLE : SPEC == SPEC_GENERIC ? a.term_kind : (int)QD_TERM_DEFAULT;
 }
+// physics substeps per env step: compile-time in the specialisations (a run-time loop keeps the whole model and the
+// controls alive across the float64 core: +46 registers, every one of them an AGPR copy per use)
+template <int SPEC> constexpr int spec_frame_skip() { return SPEC == SPEC_SIMPLE ? 2 : SPEC == SPEC_GENERIC ? 0 : 1; }
 template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
   return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : SPEC == SPEC_GENERIC ? a.ctrl_map : (int)QD_CTRL_AFFINE;
 }
@@ -336,7 +339,14 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
   if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
-  for (int k = 0; k < a.frame_skip; k++) e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  if (spec_frame_skip<SPEC>() == 1) {
+    e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  } else if (spec_frame_skip<SPEC>() == 2) {
+    e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+    e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  } else {
+    for (int k = 0; k < a.frame_skip; k++) e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
+  }
   QD_STAMP(2);
   e.flags &= ~FLAG_ACC_STALE;
   e.num_steps += 1;
@@ -369,10 +379,12 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   (void)NS;
 }
 
-// Register allocation is left uncapped (256 VGPR + ~54 AGPR, one wave per SIMD): forcing two waves per SIMD with
-// __launch_bounds__(256, 2) spills 224 B/lane to scratch and is slower at 10^6 envs (154 vs 142 us per step).
+// The 256-thread variant (>= 65536 envs, the chip is full) is capped at 256 registers so that TWO waves share a
+// SIMD and hide each other's memory latency; with the substep count known at compile time the specialised
+// instantiations fit with a few dwords of scratch.  The 64-thread variant (small batches: one wave per SIMD
+// anyway) keeps the whole register file.
 template <bool LOAD, int BLOCK, int SPEC>
-__global__ __launch_bounds__(BLOCK) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && SPEC != SPEC_GENERIC ? 2 : 1)) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
   if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
@@ -847,12 +859,13 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   e->regen = 0;
   e->spec = SPEC_GENERIC;
   if (e->load && c->obs_kind == QD_OBS_RPY_PARAMS && c->reward_kind == QD_REW_DISTANCE_ENERGY && c->ctrl_map == QD_CTRL_AFFINE &&
-      c->term_kind == QD_TERM_DEFAULT)
+      c->term_kind == QD_TERM_DEFAULT && c->frame_skip == 1)
     e->spec = SPEC_RMA;
   else if (e->load && c->obs_kind == QD_OBS_FULLSTATE && c->reward_kind == QD_REW_PEND_EN4 && c->ctrl_map == QD_CTRL_AFFINE &&
-           c->term_kind == QD_TERM_DEFAULT)
+           c->term_kind == QD_TERM_DEFAULT && c->frame_skip == 1)
     e->spec = SPEC_LSTM;
-  else if (!e->load && c->obs_kind == QD_OBS_SIMPLE && c->term_kind == QD_TERM_SIMPLE && c->ctrl_map == QD_CTRL_DIRECT)
+  else if (!e->load && c->obs_kind == QD_OBS_SIMPLE && c->term_kind == QD_TERM_SIMPLE && c->ctrl_map == QD_CTRL_DIRECT &&
+           c->frame_skip == 2)
     e->spec = SPEC_SIMPLE;
   *out = e;
   return QD_OK;

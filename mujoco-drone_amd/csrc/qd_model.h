@@ -5,7 +5,7 @@
 // compiler derive masses, centres of mass and principal inertias from the geoms.
 // Here the same quantities are derived directly from the six raw parameters
 // (mass, arm_len, motor_force, motor_tau, pendulum_len, weight_mass;
-// BaseDroneEnv.py:208-214), in float64, one drone per lane, and stored as the 13
+// BaseDroneEnv.py:208-214), in float64, one drone per lane, and stored as the 27
 // per-env float32 constants the step kernel needs.  No XML, no compile step.
 //
 // Symmetry facts used (verified against the general oracle in the tests):
