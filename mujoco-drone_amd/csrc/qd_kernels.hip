@@ -106,12 +106,14 @@ __device__ __forceinline__ void moving_reference(const KArgs& a, int i, int k, f
   ref[3] = a.ref[3];
 }
 
-template <bool LOAD>
+// WITH_ACC = false: the stored accelerometer reading is not fetched (the step kernels overwrite it)
+template <bool LOAD, bool WITH_ACC = true>
 __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   const float4* g = a.g;
   const int np = a.npad;
   const float4 pos = g[G_POS * np + i], qt = g[G_QUAT * np + i], vel = g[G_VEL * np + i], ang = g[G_ANG * np + i];
-  const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i], acc = g[G_ACC * np + i];
+  const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i];
+  const float4 acc = WITH_ACC ? g[G_ACC * np + i] : make_float4(0.f, 0.f, 0.f, 0.f);
   const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i], m3 = g[G_M3 * np + i];
   const float4 m4 = g[G_M4 * np + i];
   const float4 p0 = g[G_P0 * np + i], p1 = g[G_P1 * np + i];
@@ -402,7 +404,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && SPEC != SPEC_GENERIC ? 2 : 
   QD_STAMP(0);
   if (i < a.n) {
     EnvRegs e;
-    load_env<LOAD>(a, i, e);
+    load_env<LOAD, false>(a, i, e);
     const float4 action = reinterpret_cast<const float4*>(actions)[i];
 #ifdef QD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -443,7 +445,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
   const int wave_base = i - lane;
   const bool live = i < a.n;
   EnvRegs e;
-  if (live) load_env<LOAD>(a, i, e);
+  if (live) load_env<LOAD, false>(a, i, e);
   float4 next_action = make_float4(0.f, 0.f, 0.f, 0.f);
   if (live && T > 0) next_action = reinterpret_cast<const float4*>(actions)[i];
   for (int t = 0; t < T; t++) {
