@@ -78,8 +78,10 @@ enum Spec {
   SPEC_GENERIC = 0,
   SPEC_RMA = 1,     // train_PPO.py / train_RMA.py: LocalFrameRPYParamsEnv + distance_energy_reward      (BASELINE cfg 3, 4)
   SPEC_LSTM = 2,    // train_LSTM.py: LocalFrameFullStateEnv + distance_energy_reward_pendulum_en4          (BASELINE cfg 5)
-  SPEC_SIMPLE = 3   // SimpleDrone.py: 6-value observation, drone-0 style reward / termination, direct ctrl (BASELINE cfg 1, 2)
+  SPEC_SIMPLE = 3,  // SimpleDrone.py: 6-value observation, drone-0 style reward / termination, direct ctrl (BASELINE cfg 1, 2)
+  SPEC_GENERIC_FS1 = 4  // any observation / reward (run-time dispatch) with the usual skip_steps = 1 fixed at compile time
 };
+template <int SPEC> constexpr bool spec_runtime() { return SPEC == SPEC_GENERIC || SPEC == SPEC_GENERIC_FS1; }
 template <int SPEC> __device__ __forceinline__ int spec_obs(const KArgs& a) {
   return SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : SPEC == SPEC_LSTM ? (int)OBS_FULLSTATE : SPEC == SPEC_SIMPLE ? (int)OBS_SIMPLE : a.obs_kind;
 }
@@ -87,13 +89,13 @@ template <int SPEC> __device__ __forceinline__ int spec_reward(const KArgs& a) {
   return SPEC == SPEC_RMA ? (int)REW_DISTANCE_ENERGY : SPEC == SPEC_LSTM ? (int)REW_PEND_EN4 : SPEC == SPEC_SIMPLE ? (int)REW_SIMPLE : a.reward_kind;
 }
 template <int SPEC> __device__ __forceinline__ int spec_term(const KArgs& a) {
-  return SPEC == SPEC_SIMPLE ? (int)QD_TERM_SIMPLE : SPEC == SPEC_GENERIC ? a.term_kind : (int)QD_TERM_DEFAULT;
+  return SPEC == SPEC_SIMPLE ? (int)QD_TERM_SIMPLE : spec_runtime<SPEC>() ? a.term_kind : (int)QD_TERM_DEFAULT;
 }
 // physics substeps per env step: compile-time in the specialisations (a run-time loop keeps the whole model and the
 // controls alive across the float64 core: +46 registers, every one of them an AGPR copy per use)
 template <int SPEC> constexpr int spec_frame_skip() { return SPEC == SPEC_SIMPLE ? 2 : SPEC == SPEC_GENERIC ? 0 : 1; }
 template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
-  return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : SPEC == SPEC_GENERIC ? a.ctrl_map : (int)QD_CTRL_AFFINE;
+  return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : spec_runtime<SPEC>() ? a.ctrl_map : (int)QD_CTRL_AFFINE;
 }
 
 // gen_circle_trajectory (evaluation.py:135-138) around the configured reference, one phase per env
@@ -106,16 +108,17 @@ __device__ __forceinline__ void moving_reference(const KArgs& a, int i, int k, f
   ref[3] = a.ref[3];
 }
 
-// WITH_ACC = false: the stored accelerometer reading is not fetched (the step kernels overwrite it)
-template <bool LOAD, bool WITH_ACC = true>
+// WITH_ACC = false: the stored accelerometer reading is not fetched (the step kernels overwrite it).
+// FOLD = true: planes M3..M6 (fluid coefficients) are not fetched but re-folded from M0..M2 in float32; used by
+// the 256-thread (HBM-bound) step kernels, where 64 bytes less per env-step matter more than ~90 instructions.
+template <bool LOAD, bool WITH_ACC = true, bool FOLD = false>
 __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   const float4* g = a.g;
   const int np = a.npad;
   const float4 pos = g[G_POS * np + i], qt = g[G_QUAT * np + i], vel = g[G_VEL * np + i], ang = g[G_ANG * np + i];
   const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i];
   const float4 acc = WITH_ACC ? g[G_ACC * np + i] : make_float4(0.f, 0.f, 0.f, 0.f);
-  const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i], m3 = g[G_M3 * np + i];
-  const float4 m4 = g[G_M4 * np + i];
+  const float4 m0 = g[G_M0 * np + i], m1 = g[G_M1 * np + i], m2 = g[G_M2 * np + i];
   const float4 p0 = g[G_P0 * np + i], p1 = g[G_P1 * np + i];
   e.s.px = pos.x; e.s.py = pos.y; e.s.pz = pos.z; e.s.th1 = pos.w;
   e.s.qw = qt.x; e.s.qx = qt.y; e.s.qy = qt.z; e.s.qz = qt.w;
@@ -126,14 +129,28 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   e.acc = mk<float>(acc.x, acc.y, acc.z);
   e.M.m0 = m0.x; e.M.c0z = m0.y; e.M.I0x = m0.z; e.M.I0y = m0.w;
   e.M.I0z = m1.x; e.M.rot = m1.y; e.M.gearF = m1.z; e.M.gearT = m1.w;
-  e.M.inv_tau = m2.x; e.M.klin0 = m2.y; e.M.kang0 = m2.z; e.M.qlx0 = m2.w;
-  e.M.qly0 = m3.x; e.M.qlz0 = m3.y; e.M.qax0 = m3.z; e.M.qay0 = m3.w;
-  e.M.qaz0 = m4.x; e.M.m2 = m4.y; e.M.lc = m4.z; e.M.I2t = m4.w;
-  e.M.I2a = e.M.klin2 = e.M.kang2 = e.M.qlt2 = e.M.qla2 = e.M.qat2 = e.M.qaa2 = e.M.pad = 0.f;
-  if (LOAD) {
-    const float4 m5 = g[G_M5 * np + i], m6 = g[G_M6 * np + i];
-    e.M.I2a = m5.x; e.M.klin2 = m5.y; e.M.kang2 = m5.z; e.M.qlt2 = m5.w;
-    e.M.qla2 = m6.x; e.M.qat2 = m6.y; e.M.qaa2 = m6.z;
+  e.M.inv_tau = m2.x; e.M.m2 = m2.y; e.M.lc = m2.z; e.M.I2t = m2.w;
+  e.M.I2a = p1.z;  // the raw-parameter plane P1 carries a copy of I2a in its spare slot
+  e.M.klin2 = e.M.kang2 = e.M.qlt2 = e.M.qla2 = e.M.qat2 = e.M.qaa2 = e.M.pad = 0.f;
+  if (FOLD) {
+    fluid_coeffs_inline(e.M.I0x, e.M.I0y, e.M.I0z, e.M.m0, &e.M.klin0, &e.M.kang0, &e.M.qlx0, &e.M.qly0, &e.M.qlz0, &e.M.qax0,
+                        &e.M.qay0, &e.M.qaz0);
+    if (LOAD) {
+      float qly, qay;
+      fluid_coeffs_inline(e.M.I2t, e.M.I2t, e.M.I2a, e.M.m2, &e.M.klin2, &e.M.kang2, &e.M.qlt2, &qly, &e.M.qla2, &e.M.qat2, &qay,
+                          &e.M.qaa2);
+    }
+  } else {
+    const float4 m3 = g[G_M3 * np + i], m4 = g[G_M4 * np + i];
+    e.M.klin0 = m3.y; e.M.kang0 = m3.z; e.M.qlx0 = m3.w;
+    e.M.qly0 = m4.x; e.M.qlz0 = m4.y; e.M.qax0 = m4.z; e.M.qay0 = m4.w;
+    const float4 m5 = g[G_M5 * np + i];
+    e.M.qaz0 = m5.x;
+    if (LOAD) {
+      const float4 m6 = g[G_M6 * np + i];
+      e.M.klin2 = m5.y; e.M.kang2 = m5.z; e.M.qlt2 = m5.w;
+      e.M.qla2 = m6.x; e.M.qat2 = m6.y; e.M.qaa2 = m6.z;
+    }
   }
   e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
   if (a.ref_mode == QD_REF_CIRCLE) {
@@ -313,7 +330,7 @@ template <int SPEC> constexpr int spec_obs_dim() { return SPEC == SPEC_RMA ? 22 
 
 template <int SPEC>
 __device__ __forceinline__ void flush_obs_any(const float* tile, float* dst, int rows, int D) {
-  if (SPEC != SPEC_GENERIC && rows == 64) flush_obs_static<(spec_obs_dim<SPEC>() > 0 ? spec_obs_dim<SPEC>() : 4)>(tile, dst);
+  if (!spec_runtime<SPEC>() && rows == 64) flush_obs_static<(spec_obs_dim<SPEC>() > 0 ? spec_obs_dim<SPEC>() : 4)>(tile, dst);
   else flush_obs(tile, dst, rows, D);
 }
 
@@ -386,7 +403,7 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
 // instantiations fit with a few dwords of scratch.  The 64-thread variant (small batches: one wave per SIMD
 // anyway) keeps the whole register file.
 template <bool LOAD, int BLOCK, int SPEC>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && SPEC != SPEC_GENERIC ? 2 : 1)) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 : 1)) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
   if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && SPEC != SPEC_GENERIC ? 2 : 
   QD_STAMP(0);
   if (i < a.n) {
     EnvRegs e;
-    load_env<LOAD, false>(a, i, e);
+    load_env<LOAD, false, (BLOCK == 256)>(a, i, e);
     const float4 action = reinterpret_cast<const float4*>(actions)[i];
 #ifdef QD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -527,7 +544,7 @@ __global__ __launch_bounds__(64) void k_params(KArgs a, ParamCfg pc, uint32_t re
   for (int k = 0; k < MODEL_FLOATS / 4; k++)
     g[(G_M0 + k) * np + i] = make_float4((float)mp[4 * k], (float)mp[4 * k + 1], (float)mp[4 * k + 2], (float)mp[4 * k + 3]);
   g[G_P0 * np + i] = make_float4((float)raw[0], (float)raw[1], (float)raw[2], (float)raw[3]);
-  g[G_P1 * np + i] = make_float4((float)raw[4], (float)raw[5], 0.f, 0.f);
+  g[G_P1 * np + i] = make_float4((float)raw[4], (float)raw[5], (float)M.I2a, 0.f);
   if (fresh_data) {  // a new MjData: activations and sensordata start at zero
     g[G_ACT * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
     g[G_ACC * np + i] = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -869,6 +886,8 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   else if (!e->load && c->obs_kind == QD_OBS_SIMPLE && c->term_kind == QD_TERM_SIMPLE && c->ctrl_map == QD_CTRL_DIRECT &&
            c->frame_skip == 2)
     e->spec = SPEC_SIMPLE;
+  else if (c->frame_skip == 1)
+    e->spec = SPEC_GENERIC_FS1;
   *out = e;
   return QD_OK;
 }
@@ -1000,9 +1019,11 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
     if (env->load) {                                                         \
       if (env->spec == SPEC_RMA) QD_STEP_LAUNCH(true, BLK, SPEC_RMA);        \
       else if (env->spec == SPEC_LSTM) QD_STEP_LAUNCH(true, BLK, SPEC_LSTM); \
+      else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC_FS1); \
       else QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC);                          \
     } else {                                                                 \
       if (env->spec == SPEC_SIMPLE) QD_STEP_LAUNCH(false, BLK, SPEC_SIMPLE); \
+      else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC_FS1); \
       else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
     }                                                                        \
   } while (0)
@@ -1025,9 +1046,11 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   if (env->load) {
     if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
     else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
+    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
     else QD_ROLL(true, SPEC_GENERIC);
   } else {
     if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
+    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL

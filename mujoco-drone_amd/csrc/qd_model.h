@@ -44,12 +44,13 @@ template <class T>
 struct Model {
   T m0, c0z, I0x, I0y;           // plane M0: core mass, COM height, inertia about the COM (body axes)
   T I0z, rot, gearF, gearT;      // plane M1: |x|=|y| of the rotor sites, thrust and yaw-torque gears
-  T inv_tau, klin0, kang0, qlx0; // plane M2: 1/motor_tau, core fluid coefficients
-  T qly0, qlz0, qax0, qay0;      // plane M3
-  T qaz0, m2, lc, I2t;           // plane M4: tether+load mass, COM distance, transverse inertia
-  T I2a, klin2, kang2, qlt2;     // plane M5: axial inertia, tether fluid coefficients (t = x,y; a = z)
+  T inv_tau, m2, lc, I2t;        // plane M2: 1/motor_tau, tether+load mass, COM distance, transverse inertia
+  T I2a, klin0, kang0, qlx0;     // plane M3: axial inertia; from here on: fluid coefficients (core ..0, tether ..2)
+  T qly0, qlz0, qax0, qay0;      // plane M4
+  T qaz0, klin2, kang2, qlt2;    // plane M5 (t = x,y axes of the tether frame; a = along the tether)
   T qla2, qat2, qaa2, pad;       // plane M6
 };
+// M0..M2 (+ I2a) determine everything else: fluid_coeffs_inline() re-folds planes M3..M6 from them
 constexpr int MODEL_FLOATS = 28;
 
 // link sphere (env_gen.py:68): its inertia box is a cube of side r*sqrt(2.4)
@@ -79,6 +80,22 @@ QD_HD double round5(double x) {
     r = rint(ax / p10[k]) * p10[k];
   }
   return x < 0 ? -r : r;
+}
+
+// float32 version used inside the step kernel when streaming the folded planes would cost more (HBM-bound batches)
+template <class T>
+QD_HD void fluid_coeffs_inline(T Ix, T Iy, T Iz, T mass, T* klin, T* kang, T* qlx, T* qly, T* qlz, T* qax, T* qay, T* qaz) {
+  const T pi = T(3.14159265358979323846), rho = T(Const::density), mu = T(Const::viscosity);
+  const T k6 = T(6) * frcp(mass);
+  const T bx = qsqrt(qmax(T(1e-15), Iy + Iz - Ix) * k6), by = qsqrt(qmax(T(1e-15), Ix + Iz - Iy) * k6),
+          bz = qsqrt(qmax(T(1e-15), Ix + Iy - Iz) * k6);
+  const T d = (bx + by + bz) * T(1.0 / 3.0);
+  *klin = T(3) * pi * d * mu;
+  *kang = pi * d * d * d * mu;
+  *qlx = T(0.5) * rho * by * bz; *qly = T(0.5) * rho * bx * bz; *qlz = T(0.5) * rho * bx * by;
+  const T bx2 = bx * bx, by2 = by * by, bz2 = bz * bz;
+  const T bx4 = bx2 * bx2, by4 = by2 * by2, bz4 = bz2 * bz2, r64 = rho * T(1.0 / 64.0);
+  *qax = r64 * bx * (by4 + bz4); *qay = r64 * by * (bx4 + bz4); *qaz = r64 * bz * (bx4 + by4);
 }
 
 QD_HD void fluid_coeffs(double Ix, double Iy, double Iz, double mass, double* klin, double* kang, double ql[3], double qa[3]) {

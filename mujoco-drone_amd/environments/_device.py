@@ -166,9 +166,8 @@ class DeviceEnv:
         npad = (self.n + 255) // 256 * 256
         ngroups, first = 22, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
         g = self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
-        names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "klin0", "kang0", "qlx0",
-                 "qly0", "qlz0", "qax0", "qay0", "qaz0", "m2", "lc", "I2t", "I2a", "klin2", "kang2", "qlt2", "qla2",
-                 "qat2", "qaa2"]
+        names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "m2", "lc", "I2t", "I2a", "klin0",
+                 "kang0", "qlx0", "qly0", "qlz0", "qax0", "qay0", "qaz0", "klin2", "kang2", "qlt2", "qla2", "qat2", "qaa2"]
         flat = torch.cat([g[first + k] for k in range(7)], dim=1)
         return {k: flat[:, i].clone() for i, k in enumerate(names)}
 

@@ -60,7 +60,7 @@ def test_closed_form_model_vs_general_geom_composition(twin, orc, load):
         assert twin.twin_derive(P(raw), P(m28)) == load
         want = [m.m0, m.c0[2], m.I0full[0], m.I0full[1], m.I0full[2], m.rotor[1][0], m.gearF, m.gearT[0], 1 / m.tau]
         np.testing.assert_allclose(m28[:9], want, rtol=1e-12)
-        np.testing.assert_allclose(m28[17:21], [m.m2, m.lc, m.I2[0], m.I2[2]], rtol=1e-12, atol=1e-300)
+        np.testing.assert_allclose(m28[9:13], [m.m2, m.lc, m.I2[0], m.I2[2]], rtol=1e-12, atol=1e-300)
         # symmetry facts the closed form relies on
         assert max(abs(m.I0full[3]), abs(m.I0full[4]), abs(m.I0full[5])) < 1e-12
         assert abs(m.c0[0]) < 1e-15 and abs(m.c0[1]) < 1e-15
@@ -75,9 +75,9 @@ def test_closed_form_model_vs_general_geom_composition(twin, orc, load):
         perm = np.argmax(np.abs(R0), axis=0)          # inertial axis k lies along body axis perm[k]
         box = np.zeros(3); box[perm] = np.array(m.box0[:])
         d = box.mean()
-        np.testing.assert_allclose(m28[9:11], [3 * np.pi * d * 2e-5, np.pi * d ** 3 * 2e-5], rtol=1e-10)
-        np.testing.assert_allclose(m28[11:14], [0.6 * box[1] * box[2], 0.6 * box[0] * box[2], 0.6 * box[0] * box[1]], rtol=1e-10)
-        np.testing.assert_allclose(m28[14:17], [1.2 * box[i] * (box[(i + 1) % 3] ** 4 + box[(i + 2) % 3] ** 4) / 64 for i in range(3)], rtol=1e-10)
+        np.testing.assert_allclose(m28[13:15], [3 * np.pi * d * 2e-5, np.pi * d ** 3 * 2e-5], rtol=1e-10)
+        np.testing.assert_allclose(m28[15:18], [0.6 * box[1] * box[2], 0.6 * box[0] * box[2], 0.6 * box[0] * box[1]], rtol=1e-10)
+        np.testing.assert_allclose(m28[18:21], [1.2 * box[i] * (box[(i + 1) % 3] ** 4 + box[(i + 2) % 3] ** 4) / 64 for i in range(3)], rtol=1e-10)
 
 
 @pytest.mark.parametrize("load", [1, 0])
