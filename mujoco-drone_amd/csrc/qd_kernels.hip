@@ -256,6 +256,9 @@ __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e)
     }
   }
   if (!taken) sample_episode<LOAD>(a, i, e.episode, e.s);
+  // activations survive a reset (reference quirk C-2) -- unless they diverged: MuJoCo's bad-state check would have
+  // called mj_resetData, which zeroes them
+  if (!(fabsf(e.s.a0) + fabsf(e.s.a1) + fabsf(e.s.a2) + fabsf(e.s.a3) < 1e10f)) e.s.a0 = e.s.a1 = e.s.a2 = e.s.a3 = 0.f;
   e.episode += 1u;
   e.num_steps = 0;
   if (a.obs_needs_acc) refresh_sensor<LOAD>(a, e);

@@ -286,10 +286,12 @@ QD_HD T reward(int kind, const T* s, const T a[4], int k, const T ref[4], T max_
   }
 
 // default_termination_fcn (BaseDroneEnv.py:12-16); returned as `truncated`
+// A non-finite position also truncates: in the reference a diverged state never reaches this test because MuJoCo's
+// mj_checkPos/mj_checkAcc reset the data first (which then lies far from the reference and truncates one step later).
 template <class T>
 QD_HD bool truncated(const T* s, const T ref[4], int num_steps, T max_distance, int max_steps) {
   const V3<T> dv = mk<T>(s[0] - ref[0], s[1] - ref[1], s[2] - ref[2]);
-  return qsqrt(dot(dv, dv)) > max_distance || num_steps >= max_steps;
+  return !(qsqrt(dot(dv, dv)) <= max_distance) || num_steps >= max_steps;
 }
 
 }  // namespace qd

@@ -606,3 +606,21 @@ def test_determinism_and_long_run_stability(qd):
     assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(s).all()
     assert int(k.max()) < 256 and ntr >= 3000 * n // 256          # every env truncates at least every 256 steps
     assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(n, device=q.device), atol=1e-5)
+
+
+def test_diverged_env_is_truncated_and_recovers(qd):
+    """non-finite state (what an unstable actuator filter, h/tau > 2, produces): truncated, re-sampled, activations zeroed"""
+    L, n = qd._lib, 128
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, auto_reset=1, seed=4, max_steps=10 ** 6))
+    env.reset()
+    q, v, a, _, _ = [x.clone() for x in env.get_state()]
+    q[5, 0] = float("nan"); a[5] = float("inf"); v[9, 3] = float("nan")
+    env.set_state(q, v, a)
+    act = torch.full((n, 4), 0.5, device="cuda")
+    o, r, t = env.step(act)
+    assert int(t[5]) == 1 and int(t[9]) == 1 and int(t.sum()) == 2
+    for _ in range(3):
+        o, r, t = env.step(act)
+    q, v, a, s, k = env.get_state()
+    assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(a).all() and torch.isfinite(o).all()
+    assert int(k[5]) == 3 and int(k[0]) == 4
