@@ -64,39 +64,39 @@ def default_termination_fcn(env, state, action, num_steps):
     return bool(out[0].item())
 
 
-# same keys and values as the reference's base_config (BaseDroneEnv.py:19-50)
-base_config = {'seed': 42,
-               'frequency': 100,
-               'skip_steps': 1,
-               'reference': [0, 0, 15, 0],
-               'start_pos': [0, 0, 15, 0],
-               'max_distance': 4,
-               'random_start_pos': True,
-               'random_params': True,
-               'pendulum': True,
-               'state_difficulty': 0.4,
-               'param_difficulty': 0.1,
-               'max_random_offset': 2,
-               'rp_variance': [0.8, 0.8],
-               'vel_variance': [1, 1, 1],
-               'ang_vel_variance': [1, 1, 1],
-               'mass_interval': [1, 0.1],
-               'arm_len_interval': [0.17, 0.02],
-               'motor_force_interval': [7, 1],
-               'motor_tau_interval': [0.01, 0.0025],
-               'pendulum_length_interval': [1.2, 0.2],
-               'weight_mass_interval': [0.3, 0.05],
-               'pendulum_rp_variance': [0.5, 0.5],
-               'pendulum_ang_vel_variance': [0.5, 0.5],
-               'reward_fcn': default_reward_fcn,
-               'terminated_fcn': default_termination_fcn,
-               'max_steps': 512,
-               'regen_env_at_steps': None,
-               'train_vis': 0,
-               'window_title': 'mujoco',
-               'controlled': False,
-               'mocaps': 1
-               }
+# Same keys and values as the reference's `base_config` (BaseDroneEnv.py:19-50), grouped by what they configure.
+_SIM = dict(seed=42, frequency=100, skip_steps=1, pendulum=True, max_steps=512, regen_env_at_steps=None)
+_TASK = dict(reference=[0, 0, 15, 0], start_pos=[0, 0, 15, 0], max_distance=4, reward_fcn=default_reward_fcn,
+             terminated_fcn=default_termination_fcn)
+_RESET = dict(random_start_pos=True, state_difficulty=0.4, max_random_offset=2, rp_variance=[0.8, 0.8],
+              vel_variance=[1, 1, 1], ang_vel_variance=[1, 1, 1], pendulum_rp_variance=[0.5, 0.5],
+              pendulum_ang_vel_variance=[0.5, 0.5])
+_PARAMS = dict(random_params=True, param_difficulty=0.1, mass_interval=[1, 0.1], arm_len_interval=[0.17, 0.02],
+               motor_force_interval=[7, 1], motor_tau_interval=[0.01, 0.0025], pendulum_length_interval=[1.2, 0.2],
+               weight_mass_interval=[0.3, 0.05])
+_UI = dict(train_vis=0, window_title='mujoco', controlled=False, mocaps=1)
+base_config = {**_SIM, **_TASK, **_RESET, **_PARAMS, **_UI}
+
+# Defaults BaseDroneEnv.__init__ falls back to when a key is absent (BaseDroneEnv.py:60-106; they differ from
+# base_config on purpose -- that is how the reference behaves).  attribute name -> (config key, default)
+_ATTR_DEFAULTS = {
+    'window_title': ('window_title', 'mujoco'), 'mocaps': ('mocaps', 1), 'skip_steps': ('skip_steps', 1),
+    'frequency': ('frequency', 200), 'num_drones': ('num_drones', 1), 'pendulum': ('pendulum', True),
+    'state_difficulty': ('state_difficulty', 0.1), 'param_difficulty': ('param_difficulty', 0.1),
+    'random_start_pos': ('random_start_pos', False), 'random_params': ('random_params', False),
+    'regen_env_at_steps': ('regen_env_at_steps', None), 'max_distance': ('max_distance', 1),
+    'reward_fcn': ('reward_fcn', default_reward_fcn), 'terminated_fcn': ('terminated_fcn', default_termination_fcn),
+    'max_steps': ('max_steps', 512),
+}
+_INTERVAL_DEFAULTS = {   # [centre, half-width] of each randomised drone parameter
+    'mass_interval': [1.35, 0.15], 'arm_len_interval': [0.17, 0.02], 'motor_force_interval': [7.5, 1.5],
+    'motor_tau_interval': [0.003, 0.002], 'pendulum_length_interval': [1.2, 0.3], 'weight_mass_interval': [0.2, 0.1],
+}
+_VARIANCE_KEYS = {       # attribute -> (config key, length); all scaled by state_difficulty.  QUIRK C-3: the roll/pitch
+    'angle_variance': ('angle_variance', 2),               # key is 'angle_variance'; base_config's 'rp_variance' is never read
+    'ang_vel_variance': ('ang_vel_variance', 3), 'vel_variance': ('vel_variance', 3),
+    'pendulum_rp_variance': ('pendulum_rp_variance', 2), 'pendulum_ang_vel_variance': ('pendulum_ang_vel_variance', 2),
+}
 
 PARAM_NAMES = ('mass', 'arm_len', 'motor_force', 'motor_tau', 'pendulum_len', 'weight_mass')
 
@@ -111,36 +111,15 @@ class BaseDroneEnv(_VectorEnvBase):
             raise NotImplementedError("joystick reference control (BaseDroneEnv.py:151-172) is a human-in-the-loop UI "
                                       "and is not part of the GPU env")
         self.render_mode = None  # rendering is out of scope; render() is a no-op
-        self.window_title = config.get('window_title', 'mujoco')
-        self.mocaps = config.get('mocaps', 1)
-        self.skip_steps = config.get('skip_steps', 1)
-        self.frequency = config.get('frequency', 200)
+        for attr, (key, default) in _ATTR_DEFAULTS.items():
+            setattr(self, attr, config.get(key, default))
+        for key, default in _INTERVAL_DEFAULTS.items():
+            setattr(self, key, np.array(config.get(key, default)))
         self._reference = config.get('reference', [0, 0, 0, 0])
-        self.num_drones = config.get('num_drones', 1)
-        self.pendulum = config.get('pendulum', True)
-        self.mass_interval = np.array(config.get('mass_interval', [1.35, 0.15]))
-        self.arm_len_interval = np.array(config.get('arm_len_interval', [0.17, 0.02]))
-        self.motor_force_interval = np.array(config.get('motor_force_interval', [7.5, 1.5]))
-        self.motor_tau_interval = np.array(config.get('motor_tau_interval', [0.003, 0.002]))
-        self.pendulum_length_interval = np.array(config.get('pendulum_length_interval', [1.2, 0.3]))
-        self.weight_mass_interval = np.array(config.get('weight_mass_interval', [0.2, 0.1]))
-        self.state_difficulty = config.get('state_difficulty', 0.1)
-        self.param_difficulty = config.get('param_difficulty', 0.1)
-        self.random_start_pos = config.get('random_start_pos', False)
-        self.random_params = config.get('random_params', False)
-        self.regen_env_at_steps = config.get('regen_env_at_steps', None)
         self.start_pos = config.get('start_pos', self._reference)
-        self.max_distance = config.get('max_distance', 1)
-        self.reward_fcn = config.get('reward_fcn', default_reward_fcn)
-        self.terminated_fcn = config.get('terminated_fcn', default_termination_fcn)
-        self.max_steps = config.get('max_steps', 512)
         self.max_pos_offset = self.state_difficulty * config.get('max_random_offset', 0)
-        # QUIRK C-3: 'rp_variance' of base_config is never read; the key is 'angle_variance'
-        self.angle_variance = self.state_difficulty * np.array(config.get('angle_variance', [0, 0]))
-        self.ang_vel_variance = self.state_difficulty * np.array(config.get('ang_vel_variance', [0, 0, 0]))
-        self.vel_variance = self.state_difficulty * np.array(config.get('vel_variance', [0, 0, 0]))
-        self.pendulum_rp_variance = self.state_difficulty * np.array(config.get('pendulum_rp_variance', [0, 0]))
-        self.pendulum_ang_vel_variance = self.state_difficulty * np.array(config.get('pendulum_ang_vel_variance', [0, 0]))
+        for attr, (key, length) in _VARIANCE_KEYS.items():
+            setattr(self, attr, self.state_difficulty * np.array(config.get(key, [0] * length)))
 
         self.total_steps = 0
         # QUIRK C-4: the worker index is looked up as a dict KEY (BaseDroneEnv.py:113), which RLlib's
