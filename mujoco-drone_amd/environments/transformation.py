@@ -1,35 +1,42 @@
-"""Attitude conversions with the reference's names and conventions
-(environments/transformation.py:5-29), evaluated on the GPU (qd_transform).
+"""Attitude conversions evaluated on the GPU (C ABI `qd_transform`), exported under the names the reference's
+`environments/transformation.py` uses (reference lines 5-29) so that `from environments.transformation import ...`
+keeps working.
 
-MuJoCo quaternions are (w,x,y,z); rpy is [roll, pitch, yaw] of the intrinsic ZYX
-decomposition R = Rz(yaw) Ry(pitch) Rx(roll); the pendulum rotation is Rx(r) Ry(p).
-Each function takes one vector/matrix like the reference, or a batch of rows."""
+Conventions (pinned by golden vectors from the reference): quaternions are MuJoCo-ordered (w, x, y, z);
+`rpy` = [roll, pitch, yaw] of the intrinsic Z-Y-X decomposition R = Rz(yaw) Ry(pitch) Rx(roll); the tether
+orientation is R = Rx(roll) Ry(pitch).  Every function accepts one vector / matrix or a batch of rows and
+returns float64 numpy arrays."""
+import numpy as np
+
 from .. import _lib as L
 from ._device import transform
 
-
-def mujoco_DCM2quat(DCM):
-    """rotation matrix -> MuJoCo quaternion (transformation.py:5-8)"""
-    return transform(L.TF_DCM2QUAT, DCM, 9, 4)
-
-
-def mujoco_quat2DCM(quat):
-    """MuJoCo quaternion -> rotation matrix (transformation.py:11-13)"""
-    import numpy as np
-    out = transform(L.TF_QUAT2DCM, quat, 4, 9)
-    return out.reshape(3, 3) if np.ndim(quat) == 1 else out.reshape(-1, 3, 3)
+_TABLE = {
+    # exported name: (transform id, input row length, output row length, output item shape or None)
+    "mujoco_DCM2quat": (L.TF_DCM2QUAT, 9, 4, None),
+    "mujoco_quat2DCM": (L.TF_QUAT2DCM, 4, 9, (3, 3)),
+    "mujoco_quat2rpy": (L.TF_QUAT2RPY, 4, 3, None),
+    "mujoco_rpy2quat": (L.TF_RPY2QUAT, 3, 4, None),
+    "mujoco_pendulumrp2quat": (L.TF_PENDRP2QUAT, 2, 4, None),
+}
 
 
-def mujoco_quat2rpy(quat):
-    """MuJoCo quaternion -> [roll, pitch, yaw] (transformation.py:16-18)"""
-    return transform(L.TF_QUAT2RPY, quat, 4, 3)
+def _make(name):
+    which, n_in, n_out, item = _TABLE[name]
+
+    def convert(x):
+        out = transform(which, x, n_in, n_out)
+        if item is None:
+            return out
+        single = np.ndim(x) == 1
+        return out.reshape(item) if single else out.reshape((-1,) + item)
+
+    convert.__name__ = convert.__qualname__ = name
+    convert.__doc__ = "%s: rows of %d values -> rows of %d values, computed by the device kernel k_transform" % (name, n_in, n_out)
+    return convert
 
 
-def mujoco_rpy2quat(rpy):
-    """[roll, pitch, yaw] -> MuJoCo quaternion (transformation.py:21-24)"""
-    return transform(L.TF_RPY2QUAT, rpy, 3, 4)
-
-
-def mujoco_pendulumrp2quat(pendulum_rp):
-    """pendulum [roll, pitch] (intrinsic XY) -> MuJoCo quaternion (transformation.py:27-29)"""
-    return transform(L.TF_PENDRP2QUAT, pendulum_rp, 2, 4)
+for _name in _TABLE:
+    globals()[_name] = _make(_name)
+del _name
+__all__ = list(_TABLE)
