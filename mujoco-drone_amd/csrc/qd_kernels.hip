@@ -19,6 +19,7 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -777,6 +778,13 @@ static int fail(int code, const char* fmt, ...) {
   if (!(env)) return fail(QD_ERR_INVALID, "null env handle")
 
 static inline int blocks64(int n) { return (n + 63) / 64; }
+// batch size from which the 256-thread (two waves per SIMD, re-folded coefficients) step kernel is used.
+// Measured crossover on MI355X: 65536 envs 8.6 us (64-thread) vs 9.3 us (256-thread), 131072 envs 14.4 vs 12.6 us.
+// QD_BLOCK_THRESHOLD overrides it for experiments.
+static int qd_block_threshold() {
+  static const int v = [] { const char* e = getenv("QD_BLOCK_THRESHOLD"); return e ? atoi(e) : 98304; }();
+  return v;
+}
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 extern "C" {
@@ -1008,8 +1016,8 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   const KArgs& k = env->ka;
   if (n_action_values != (int64_t)4 * k.n) return fail(QD_ERR_SHAPE, "Action dimension mismatch");
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
-  // one wavefront per workgroup while the batch is small (spreads 64 waves over 64 CUs);
-  // 256-thread workgroups once there are enough waves to fill the chip several times over
+  // one wavefront per workgroup while the batch fits the chip once (1024 SIMDs x 64 lanes = 65536 envs: every wave
+  // has a SIMD to itself); 256-thread workgroups capped at 256 registers beyond that (two waves per SIMD)
 #define QD_STEP_LAUNCH(LOADV, BLK, SPECV)                                                                         \
   do {                                                                                                            \
     KArgs kk = k;                                                                                                 \
@@ -1030,7 +1038,7 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
       else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
     }                                                                        \
   } while (0)
-  if (k.n >= 65536) QD_STEP_BLOCK(256);
+  if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(256);
   else QD_STEP_BLOCK(64);
 #undef QD_STEP_BLOCK
 #undef QD_STEP_LAUNCH

@@ -3,7 +3,9 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench
-for n in (4096, 16384, 65536, 262144, 1048576, 4194304):
+import os
+SIZES = [int(x) for x in os.environ.get('QD_SWEEP', '4096,16384,65536,262144,1048576,4194304').split(',')]
+for n in SIZES:
     env, alg = bench.make_env("config3", n, 7, "cuda:0")
     env.vector_reset_tensor()
     a = torch.rand((4, n, 4), device="cuda")
