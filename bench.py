@@ -71,7 +71,27 @@ def cpu_share():
     return int(os.environ.get("QD_CPU_THREADS", min(n, 16)))
 
 
-def cpu_baseline(seconds_target=12.0):
+def measured_copy_gbps(device):
+    """device-to-device copy bandwidth of this box (read + write bytes), the practical HBM ceiling"""
+    import torch
+    a = torch.empty(256 * 1024 * 1024, dtype=torch.float32, device=device)   # 1 GiB
+    b = torch.empty_like(a)
+    for _ in range(2):
+        b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    e0.record()
+    for _ in range(5):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    gbps = 5 * 2 * a.numel() * 4 / (e0.elapsed_time(e1) * 1e-3) / 1e9
+    del a, b
+    torch.cuda.empty_cache()
+    return gbps
+
+
+def cpu_baseline(seconds_target=12.0, threads=None):
     """the oracle (C float64 port of the same step) on the host cores, config 3 at 4096 envs"""
     import numpy as np
     from oracle import oracle as orc
@@ -83,7 +103,7 @@ def cpu_baseline(seconds_target=12.0):
     b = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameRPYParamsEnv"), L.REWARD_KINDS.index("distance_energy_reward"),
                   0.01, 1, 1, [0, 0, 15, 0], 4.0, 1024)
     b.qpos[:, 2] = 15.0
-    cores = cpu_share()
+    cores = threads or cpu_share()
     acts = rng.uniform(0, 1, (8, n, 4))
     b.step(acts[0], threads=cores)
     t0 = time.perf_counter()
@@ -274,7 +294,8 @@ def main():
                "config": {"workload": WORKLOADS[args.config] + ("; trajectories written in place into [T=%d,N,...] fragments (their RCCL all-gather is reported separately in config.trajectory_all_gather)" % T
                                                                  if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": "one HIP kernel launch per step through qd_step (C ABI)", "parallelism": "env-sharded x%d" % world,
+                          "launch": "one HIP kernel launch per step through qd_step (C ABI)",
+                          "precision": "float32 state / trigonometry / drag / integration, float64 inertia assembly and solves (load model)", "parallelism": "env-sharded x%d" % world,
                           "trajectory_all_gather": gather_info}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
         # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
@@ -292,10 +313,12 @@ def main():
                 traffic = json.load(open(pmc)).get(args.config, {}).get(str(n))
             except Exception:
                 traffic = None
+        copy_gbps = measured_copy_gbps(device)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
                            "kernel_us": kus, "isolated_launch_us": iso_us, "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
-                           "env_steps_per_launch": n, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
+                           "env_steps_per_launch": n, "measured_copy_GBps": copy_gbps,
+                           "frac_of_measured_copy": achieved / copy_gbps, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                            "WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
                            "note": "4096 envs = 64 wavefronts on 1024 SIMDs: the launch is latency/occupancy-bound, "
                                    "not HBM-bound (see DESIGN.md and the env-count sweep in `extras`)"}
@@ -347,6 +370,11 @@ def main():
             out["extras"] = extras
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline()
+            one = cpu_baseline(seconds_target=3.0, threads=1)
+            out["cpu_baseline"]["single_core_value"] = one["value"]
+            out["cpu_baseline"]["reference_python_overhead_bound"] = (
+                "the reference's own per-step Python (state extraction + obs + reward, physics excluded) measured in "
+                "BASELINE.md section 2 caps it at <= 1.25e4 env steps/s per process")
         elif world > 1:
             out["cpu_baseline"] = None
     if world > 1:
