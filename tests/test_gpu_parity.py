@@ -624,3 +624,25 @@ def test_diverged_env_is_truncated_and_recovers(qd):
     q, v, a, s, k = env.get_state()
     assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(a).all() and torch.isfinite(o).all()
     assert int(k[5]) == 3 and int(k[0]) == 4
+
+
+def test_simple_drone_multi_drone_reset_placement(qd):
+    """SimpleDrone.reset_model (SimpleDrone.py:63-72): U(+-0.03) on every qpos coordinate (quaternion left unnormalised),
+    U(+-0.01) on qvel, and `qpos[:3] = start_pos` moves ONLY drone 0; the others stay on the spawn grid (env_gen.py:116-124)"""
+    from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
+    env = SimpleDrone(num_drones=4, reference=[0, 0, 1])
+    ob = env.reset()
+    assert ob.shape == (24,)
+    d = env.data
+    q = d.qpos.reshape(4, 7); v = d.qvel.reshape(4, 6)
+    np.testing.assert_allclose(q[0, :3], [0, 0, 1], atol=1e-7)
+    grid = np.array([[-0.25, -0.25], [0.25, -0.25], [-0.25, 0.25], [0.25, 0.25]])   # sz = 2, spacing 0.5, index k -> (k % sz, k // sz)
+    assert np.all(np.abs(q[1:, :2] - grid[1:]) <= 0.03 + 1e-6) and np.all(np.abs(q[1:, 2] - 0.15) <= 0.03 + 1e-6)
+    assert np.all(np.abs(q[:, 3] - 1.0) <= 0.03 + 1e-6) and np.all(np.abs(q[:, 4:7]) <= 0.03 + 1e-6)
+    assert np.abs(np.linalg.norm(q[:, 3:7], axis=1) - 1).max() > 1e-4               # not renormalised
+    assert np.all(np.abs(v) <= 0.01 + 1e-7) and np.all(d.act == 0)
+    ob2, rew, term, info = env.step(np.full(16, 0.7))
+    assert ob2.shape == (24,) and isinstance(rew, float) and isinstance(term, bool)
+    assert abs(rew - (0.1 - np.linalg.norm(ob2[:3] - [0, 0, 1]))) < 1e-5            # drone 0 only
+    ob3 = env.reset()                                                                # a new episode draws new noise
+    assert not np.allclose(ob3[6:], ob[6:])
