@@ -164,6 +164,24 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated,
                void* stream);
 
+/* ---- the analytic cascaded PID as an on-device action source ----------------
+ * models/Analytic/PositionController.py:6-34 + AttitudeController.py:7-55, wired as
+ * attitude_test.py:26-47: masses = mass + weight_mass + 0.2*pendulum_len, forces = motor_force,
+ * inputs = entries 0:6 of the drone state vector, target = the env's (per-env / moving) reference,
+ * env action = clip(ctrl - 0.1, 0, 1).  The controller memory (integrators, previous errors,
+ * first-step flags) lives in the arena, one controller pair per env.
+ * qd_pid_reset   : fresh PositionController / AttittudeController objects (mask[N] nullable = all).
+ *                  qd_init does this once; env resets do NOT (the reference's objects are separate),
+ *                  except for envs auto-reset inside qd_rollout_pid.
+ * qd_pid_action  : one controller evaluation on the current state -> actions[N,4]; memory advances.
+ * qd_rollout_pid : T closed-loop steps (controller -> vector_step) in ONE launch: obs[T,N,D],
+ *                  reward[T,N], truncated[T,N], actions_out[T,N,4] (nullable).  Same results as
+ *                  T x (qd_pid_action, qd_step).  QD_ERR_UNSUPPORTED for SimpleDrone configurations. */
+int qd_pid_reset(qd_env* env, const uint8_t* mask, void* stream);
+int qd_pid_action(qd_env* env, float* actions, void* stream);
+int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out,
+                   void* stream);
+
 /* _get_obs() on the current simulator state, obs[N,D] */
 int qd_observe(qd_env* env, float* obs, void* stream);
 /* get_drone_states() (BaseDroneEnv.py:357-380): states[N, qd_state_dim(model)] */

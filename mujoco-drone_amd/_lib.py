@@ -73,6 +73,9 @@ SIGNATURES = {
     "qd_get_state": (_I, [_VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_step": (_I, [_VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "qd_rollout": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "qd_pid_reset": (_I, [_VP, _VP, _VP]),
+    "qd_pid_action": (_I, [_VP, _VP, _VP]),
+    "qd_rollout_pid": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),
     "qd_drone_states": (_I, [_VP, _VP, _VP]),
     "qd_eval_obs": (_I, [_I, _I, _VP, _D4, _VP, _I, _VP]),

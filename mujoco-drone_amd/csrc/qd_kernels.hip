@@ -28,6 +28,7 @@
 #include "qd_math.h"
 #include "qd_model.h"
 #include "qd_obsrew.h"
+#include "qd_pid.h"
 #include "qd_rng.h"
 
 namespace qd {
@@ -35,6 +36,7 @@ namespace qd {
 enum Group {
   G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_M4, G_M5, G_M6, G_P0, G_P1, G_REF,
   G_NX0, G_NX1, G_NX2, G_NX3, G_NX4,  // pre-sampled initial state of each env's next episode (filled by sampler waves)
+  G_C0, G_C1, G_C2, G_C3,             // memory of the analytic PID cascade (qd_pid.h); touched only by the qd_pid_* entry points
   NUM_GROUPS
 };
 constexpr int RAW_PLANES = 6;
@@ -491,6 +493,90 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
   if (live) store_env(a, i, e);
 }
 
+// ---- analytic PID cascade (models/Analytic/*.py driven as attitude_test.py:36-47) ----
+__device__ __forceinline__ void load_pid(const KArgs& a, int i, PidState<float>& c) {
+  const float4 c0 = a.g[G_C0 * a.npad + i], c1 = a.g[G_C1 * a.npad + i], c2 = a.g[G_C2 * a.npad + i], c3 = a.g[G_C3 * a.npad + i];
+  c.pos_i[0] = c0.x; c.pos_i[1] = c0.y; c.pos_i[2] = c0.z; c.first = __float_as_uint(c0.w);
+  c.pos_prev[0] = c1.x; c.pos_prev[1] = c1.y; c.pos_prev[2] = c1.z;
+  c.att_i[0] = c2.x; c.att_i[1] = c2.y; c.att_i[2] = c2.z;
+  c.att_prev[0] = c3.x; c.att_prev[1] = c3.y; c.att_prev[2] = c3.z;
+}
+__device__ __forceinline__ void store_pid(const KArgs& a, int i, const PidState<float>& c) {
+  a.g[G_C0 * a.npad + i] = make_float4(c.pos_i[0], c.pos_i[1], c.pos_i[2], __uint_as_float(c.first));
+  a.g[G_C1 * a.npad + i] = make_float4(c.pos_prev[0], c.pos_prev[1], c.pos_prev[2], 0.f);
+  a.g[G_C2 * a.npad + i] = make_float4(c.att_i[0], c.att_i[1], c.att_i[2], 0.f);
+  a.g[G_C3 * a.npad + i] = make_float4(c.att_prev[0], c.att_prev[1], c.att_prev[2], 0.f);
+}
+// the controller's inputs are entries 0:6 of the drone state vector (get_drone_states: xyz, rpy of the normalised quaternion)
+__device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRegs& e) {
+  const float qn = frsq(e.s.qw * e.s.qw + e.s.qx * e.s.qx + e.s.qy * e.s.qy + e.s.qz * e.s.qz);
+  const float xyz[3] = {e.s.px, e.s.py, e.s.pz};
+  float rpy[3], act[4];
+  quat2rpy(e.s.qw * qn, e.s.qx * qn, e.s.qy * qn, e.s.qz * qn, &rpy[0], &rpy[1], &rpy[2]);
+  pid_action(c, e.ref, xyz, rpy, pid_mass(e.par), pid_motor_force(e.par), act);
+  return make_float4(act[0], act[1], act[2], act[3]);
+}
+
+__global__ __launch_bounds__(64) void k_pid_reset(KArgs a, const uint8_t* __restrict__ mask) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n || (mask && !mask[i])) return;
+  PidState<float> c;
+  pid_reset(c);
+  store_pid(a, i, c);
+}
+
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_pid_action(KArgs a, float* __restrict__ actions) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  EnvRegs e;
+  load_env<LOAD, false, true>(a, i, e);
+  PidState<float> c;
+  load_pid(a, i, c);
+  reinterpret_cast<float4*>(actions)[i] = pid_env_action(c, e);
+  store_pid(a, i, c);
+}
+
+// T closed-loop steps per launch: controller and env state both stay in registers between steps
+template <bool LOAD, int SPEC>
+__global__ __launch_bounds__(64) void k_rollout_pid(KArgs a, int T, float* __restrict__ obs, float* __restrict__ reward,
+                                                    uint8_t* __restrict__ trunc, float* __restrict__ actions_out) {
+  __shared__ float tile[OBS_LDS_FLOATS];
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wave_base = i - lane;
+  const bool live = i < a.n;
+  EnvRegs e;
+  PidState<float> c;
+  if (live) {
+    load_env<LOAD, false>(a, i, e);
+    load_pid(a, i, c);
+  }
+  for (int t = 0; t < T; t++) {
+    if (live) {
+      if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, e.num_steps, e.ref);
+      const float4 action = pid_env_action(c, e);
+      if (actions_out) reinterpret_cast<float4*>(actions_out)[(size_t)t * a.n + i] = action;
+      float r;
+      uint8_t tr;
+      env_step<LOAD, SPEC>(a, i, e, action, tile + lane * a.D, &r, &tr);
+      if (a.auto_reset && tr) pid_reset(c);  // a new episode starts with fresh controller objects
+      reward[(size_t)t * a.n + i] = r;
+      trunc[(size_t)t * a.n + i] = tr;
+    }
+    __builtin_amdgcn_wave_barrier();
+    if (wave_base < a.n) {
+      const int rows = min(64, a.n - wave_base);
+      flush_obs_any<SPEC>(tile, obs + ((size_t)t * a.n + wave_base) * a.D, rows, a.D);
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+  if (live) {
+    store_env(a, i, e);
+    store_pid(a, i, c);
+  }
+}
+
 // _get_obs() of the current state for every env (also used after reset / regen)
 template <bool LOAD, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_observe(KArgs a, float* __restrict__ obs) {
@@ -575,6 +661,9 @@ __global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
     g[G_AUX * np + i] = make_float4(0.f, __int_as_float(0), __uint_as_float(0u), 0.f);
     g[G_REF * np + i] = make_float4(a.ref[0], a.ref[1], a.ref[2], a.ref[3]);
     g[G_NX4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+    PidState<float> c;
+    pid_reset(c);
+    store_pid(a, i, c);
   } else {
     float4 aux = g[G_AUX * np + i];
     aux.x = 0.f;
@@ -1062,6 +1151,47 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   } else {
     if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
+    else QD_ROLL(false, SPEC_GENERIC);
+  }
+#undef QD_ROLL
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_pid_reset(qd_env* env, const uint8_t* mask, void* stream) {
+  QD_NEED(env);
+  QD_LAUNCH(k_pid_reset, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, mask);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_pid_action(qd_env* env, float* actions, void* stream) {
+  QD_NEED(env);
+  if (!actions) return fail(QD_ERR_INVALID, "null output");
+  if (env->ka.term_kind == QD_TERM_SIMPLE) return fail(QD_ERR_UNSUPPORTED, "the PID cascade drives BaseDroneEnv models (attitude_test.py), not SimpleDrone");
+  const dim3 grid(blocks64(env->ka.n)), block(64);
+  if (env->load) QD_LAUNCH(k_pid_action<true>, grid, block, 0, S(stream), env->ka, actions);
+  else QD_LAUNCH(k_pid_action<false>, grid, block, 0, S(stream), env->ka, actions);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out, void* stream) {
+  QD_NEED(env);
+  const KArgs& k = env->ka;
+  if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
+  if (T == 0) return QD_OK;
+  if (!obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  if (env->ka.term_kind == QD_TERM_SIMPLE) return fail(QD_ERR_UNSUPPORTED, "the PID cascade drives BaseDroneEnv models (attitude_test.py), not SimpleDrone");
+  const dim3 grid(blocks64(k.n)), block(64);
+#define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout_pid<LOADV, SPECV>), grid, block, 0, S(stream), k, T, obs, reward, truncated, actions_out)
+  if (env->load) {
+    if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
+    else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
+    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
+    else QD_ROLL(true, SPEC_GENERIC);
+  } else {
+    if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL

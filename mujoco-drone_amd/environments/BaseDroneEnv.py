@@ -424,6 +424,27 @@ class BaseDroneEnv(_VectorEnvBase):
         self._obs_host = None
         return out
 
+    # ---- the reference's analytic PID cascade as an on-device action source (attitude_test.py:26-47) ----
+    def pid_reset(self, mask=None):
+        """fresh PositionController / AttittudeController objects for all envs (or those with mask != 0)"""
+        self._dev.pid_reset(mask)
+
+    def pid_action_tensor(self):
+        """one evaluation of the cascade on the current state -> env actions [N,4] (controller memory advances):
+        posc.compute_control -> attc.tilts2rpy -> attc.compute_control -> clip(action - 0.1, 0, 1)"""
+        self._push_reference()
+        return self._dev.pid_action()
+
+    def rollout_pid_tensor(self, T, want_actions=False):
+        """T closed-loop steps of attitude_test.py's loop in one kernel launch:
+        (obs [T,N,D], reward [T,N], truncated [T,N][, actions [T,N,4]])"""
+        self._push_reference()
+        out = self._dev.rollout_pid(T, want_actions)
+        self.total_steps += int(T)
+        self._invalidate()
+        self._obs_host = None
+        return out
+
     def reset_mask_tensor(self, mask):
         """re-sample the envs with mask != 0 (device tensor); returns fresh observations [N,D]"""
         obs = self._dev.reset(mask, want_obs=True)

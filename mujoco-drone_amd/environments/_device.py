@@ -151,6 +151,30 @@ class DeviceEnv:
                                     self._stream()))
         return obs, reward, truncated
 
+    # ---- the analytic PID cascade as an on-device action source (models/Analytic/*.py, attitude_test.py:26-47)
+    def pid_reset(self, mask=None):
+        if mask is not None:
+            mask = mask.to(device=self.device, dtype=torch.uint8).contiguous()
+            if mask.numel() != self.n:
+                raise ValueError("mask must have one entry per env")
+        L.check(self.lib.qd_pid_reset(self.handle, _ptr(mask) if mask is not None else None, self._stream()))
+
+    def pid_action(self, out=None):
+        out = torch.empty((self.n, 4), dtype=torch.float32, device=self.device) if out is None else out
+        L.check(self.lib.qd_pid_action(self.handle, _ptr(out), self._stream()))
+        return out
+
+    def rollout_pid(self, T, want_actions=False):
+        T = int(T)
+        kw = dict(device=self.device)
+        obs = torch.empty((T, self.n, self.D), dtype=torch.float32, **kw)
+        reward = torch.empty((T, self.n), dtype=torch.float32, **kw)
+        truncated = torch.empty((T, self.n), dtype=torch.uint8, **kw)
+        actions = torch.empty((T, self.n, 4), dtype=torch.float32, **kw) if want_actions else None
+        L.check(self.lib.qd_rollout_pid(self.handle, T, _ptr(obs), _ptr(reward), _ptr(truncated),
+                                        _ptr(actions) if want_actions else None, self._stream()))
+        return (obs, reward, truncated, actions) if want_actions else (obs, reward, truncated)
+
     def observe(self, out=None):
         out = self.obs if out is None else out
         L.check(self.lib.qd_observe(self.handle, _ptr(out), self._stream()))
@@ -164,7 +188,7 @@ class DeviceEnv:
     def model_constants(self):
         """per-env derived model constants (qd_model.h), read straight from the arena planes"""
         npad = (self.n + 255) // 256 * 256
-        ngroups, first = 22, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
+        ngroups, first = 26, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
         g = self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
         names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "m2", "lc", "I2t", "I2a", "klin0",
                  "kang0", "qlx0", "qly0", "qlz0", "qax0", "qay0", "qaz0", "klin2", "kang2", "qlt2", "qla2", "qat2", "qaa2"]

@@ -101,6 +101,9 @@ def _setup(lib):
     lib.orc_sample_draws_philox.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_float),
                                             C.POINTER(C.c_float)]
     lib.orc_sample_draws_philox.restype = None
+    for f in (lib.orc_pid_reset, lib.orc_pid_position, lib.orc_pid_tilts2rpy, lib.orc_pid_attitude,
+              lib.orc_pid_action):
+        f.restype = None
     return lib
 
 
@@ -271,6 +274,53 @@ def gen_params_philox(seed, env, regen, center, width, difficulty, random_params
     lib().orc_gen_params_philox(int(seed), int(env), int(regen), _p(center), _p(width), float(difficulty),
                                 int(bool(random_params)), int(bool(load)), _p(raw))
     return raw
+
+
+class OrcPid(C.Structure):
+    _fields_ = [("pos_i", C.c_double * 3), ("pos_prev", C.c_double * 3), ("att_i", C.c_double * 3),
+                ("att_prev", C.c_double * 3), ("pos_first", C.c_int), ("att_first", C.c_int)]
+
+
+class Pid:
+    """The reference's PositionController + AttittudeController pair for n drones
+    (models/Analytic/*.py, driven as attitude_test.py:36-47)."""
+
+    def __init__(self, masses, forces):
+        self.masses, self.forces = _f64(masses).ravel(), _f64(forces).ravel()
+        self.n = len(self.masses)
+        self.c = (OrcPid * self.n)()
+        for i in range(self.n):
+            lib().orc_pid_reset(C.byref(self.c[i]))
+
+    def position(self, ref, xyz):
+        ref, xyz, out = _f64(ref), _f64(xyz).reshape(self.n, 3), np.zeros((self.n, 3))
+        for i in range(self.n):
+            lib().orc_pid_position(C.byref(self.c[i]), _p(ref), _p(xyz[i]), _p(out[i]))
+        return out
+
+    @staticmethod
+    def tilts2rpy(pos_action, heading):
+        pa = _f64(pos_action).reshape(-1, 3)
+        out = np.zeros((len(pa), 4))
+        for i in range(len(pa)):
+            lib().orc_pid_tilts2rpy(_p(pa[i]), C.c_double(float(heading)), _p(out[i]))
+        return out
+
+    def attitude(self, rpyz, rpy):
+        rpyz, rpy, out = _f64(rpyz).reshape(self.n, 4), _f64(rpy).reshape(self.n, 3), np.zeros((self.n, 4))
+        for i in range(self.n):
+            lib().orc_pid_attitude(C.byref(self.c[i]), _p(rpyz[i]), _p(rpy[i]), C.c_double(self.masses[i]),
+                                   C.c_double(self.forces[i]), _p(out[i]))
+        return out
+
+    def action(self, ref, xyz, rpy):
+        """state -> env action, clip(ctrl - 0.1, 0, 1) included (attitude_test.py:47)"""
+        ref, xyz, rpy = _f64(ref), _f64(xyz).reshape(self.n, 3), _f64(rpy).reshape(self.n, 3)
+        out = np.zeros((self.n, 4))
+        for i in range(self.n):
+            lib().orc_pid_action(C.byref(self.c[i]), _p(ref), _p(xyz[i]), _p(rpy[i]), C.c_double(self.masses[i]),
+                                 C.c_double(self.forces[i]), _p(out[i]))
+        return out
 
 
 class Batch:

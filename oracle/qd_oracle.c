@@ -1048,3 +1048,73 @@ void orc_batch_step(const OrcBatchCfg *c, const OrcModel *models, const double *
     orc_obs(c->obs_kind, s, ns, c->ref, obs + (size_t)D * i);
   }
 }
+
+/* ------------------------------------------------ analytic PID cascade (8f-3) */
+static double clip3(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
+void orc_pid_reset(OrcPid *c) {
+  memset(c, 0, sizeof *c);
+  c->pos_first = c->att_first = 1;
+}
+void orc_pid_position(OrcPid *c, const double ref[3], const double xyz[3], double out[3]) {
+  /* PositionController.py:19-34 */
+  static const double P[3] = {0.4, 0.4, 0.6}, I[3] = {0.0, 0.0, 0.01}, D[3] = {0.15, 0.15, 0.2};
+  const double dt = 0.02;
+  for (int k = 0; k < 3; k++) {
+    double e = clip3(ref[k] - xyz[k], -2, 2);
+    if (c->pos_first) c->pos_prev[k] = e;
+    double ed = (e - c->pos_prev[k]) / dt;
+    c->pos_prev[k] = e;
+    c->pos_i[k] = clip3(c->pos_i[k] + dt * e, -1, 1);
+    double o = P[k] * e + I[k] * c->pos_i[k] + D[k] * ed;
+    out[k] = k < 2 ? clip3(o, -0.5, 0.5) : clip3(o, -2, 2);
+  }
+  c->pos_first = 0;
+}
+void orc_pid_tilts2rpy(const double pa[3], double heading, double rpyz[4]) {
+  /* AttitudeController.py:24-39.  Rd = [y x z, y, z] with y = z x heading is NOT orthonormal: |y| = |y x z| = s < 1,
+   * i.e. Rd = Q diag(s, s, 1) with Q orthonormal and right-handed.  scipy (1.15.3, the version the golden vectors
+   * were generated with) orthogonalises from_matrix input by the orthogonal-Procrustes / polar factor, which for
+   * Q * (positive diagonal) is exactly Q: normalise the y column.  (scipy < 1.4-era releases applied Markley's
+   * formula to the raw matrix instead; the reference pins no scipy version, the golden vectors pin this one.) */
+  double zacc = pa[2] + 9.81;
+  double t[3] = {tan(pa[0]), tan(pa[1]), 1.0};
+  double tn = sqrt(t[0] * t[0] + t[1] * t[1] + 1.0);
+  double z[3] = {t[0] / tn, t[1] / tn, 1.0 / tn}, hv[3] = {cos(heading), sin(heading), 0.0}, y[3], x[3];
+  v3cross(z, hv, y);
+  double yn = sqrt(v3dot(y, y));
+  for (int k = 0; k < 3; k++) y[k] /= yn;
+  v3cross(y, z, x);
+  double R[9] = {x[0], y[0], z[0], x[1], y[1], z[1], x[2], y[2], z[2]}, q[4];
+  orc_dcm2quat(R, q);
+  orc_quat2rpy(q, rpyz);
+  rpyz[3] = tn * fabs(zacc);
+}
+void orc_pid_attitude(OrcPid *c, const double rpyz[4], const double rpy[3], double mass, double motor_force,
+                      double ctrl[4]) {
+  /* AttitudeController.py:41-55 */
+  static const double P[3] = {2, 2, 0.1}, I[3] = {0, 0, 0}, D[3] = {0.2, 0.2, 0};
+  static const double mixer[4][3] = {{-1, -1, 1}, {1, -1, -1}, {1, 1, 1}, {-1, 1, -1}};
+  const double dt = 0.02;
+  double a[3];
+  for (int k = 0; k < 3; k++) {
+    double e = rpyz[k] - rpy[k];
+    if (c->att_first) c->att_prev[k] = e;
+    double ed = (e - c->att_prev[k]) / dt;
+    c->att_prev[k] = e;
+    c->att_i[k] = clip3(c->att_i[k] + dt * e, -1, 1);
+    a[k] = P[k] * e + I[k] * c->att_i[k] + D[k] * ed;
+  }
+  c->att_first = 0;
+  for (int m = 0; m < 4; m++) {
+    double f = mixer[m][0] * a[0] + mixer[m][1] * a[1] + mixer[m][2] * a[2] + 0.25 * rpyz[3] * mass;
+    ctrl[m] = clip3(f / motor_force, 0, 1);
+  }
+}
+void orc_pid_action(OrcPid *c, const double ref[4], const double xyz[3], const double rpy[3], double mass,
+                    double motor_force, double action[4]) {
+  double pa[3], rpyz[4];
+  orc_pid_position(c, ref, xyz, pa);
+  orc_pid_tilts2rpy(pa, ref[3], rpyz);
+  orc_pid_attitude(c, rpyz, rpy, mass, motor_force, action);
+  for (int m = 0; m < 4; m++) action[m] = clip3(action[m] - 0.1, 0, 1);
+}

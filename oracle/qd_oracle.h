@@ -163,6 +163,24 @@ void orc_batch_step(const OrcBatchCfg *c, const OrcModel *models, const double *
                     const double *actions, double *obs, double *reward, unsigned char *trunc,
                     int threads);
 
+/* ---- the analytic cascaded PID used as a closed-loop action source
+ * (models/Analytic/PositionController.py:6-34, AttitudeController.py:7-55,
+ * driven as attitude_test.py:36-47).  One OrcPid per drone = the per-drone column
+ * of the reference's controller objects.  Pinned by tests/golden pid_* vectors. */
+typedef struct OrcPid {
+  double pos_i[3], pos_prev[3];   /* PositionController.error_i / error_prev  */
+  double att_i[3], att_prev[3];   /* AttittudeController.error_i / error_prev */
+  int    pos_first, att_first;    /* first_step flags                         */
+} OrcPid;
+void orc_pid_reset(OrcPid *c);
+void orc_pid_position(OrcPid *c, const double ref[3], const double xyz[3], double out[3]);
+void orc_pid_tilts2rpy(const double pos_action[3], double heading_ref, double rpyz[4]);
+void orc_pid_attitude(OrcPid *c, const double rpyz[4], const double rpy[3], double mass, double motor_force,
+                      double ctrl[4]);
+/* attitude_test.py:38-47: state -> env action (= clip(ctrl - 0.1, 0, 1)) */
+void orc_pid_action(OrcPid *c, const double ref[4], const double xyz[3], const double rpy[3], double mass,
+                    double motor_force, double action[4]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -316,6 +316,30 @@ def main():
     out["sd_qpos"], out["sd_obs"] = qpos, np.asarray(ob)
     out["sd_reward"], out["sd_terminated"] = np.float64(rew), np.bool_(term)
 
+    # ------------------------------------------------------------------ 8f-3: analytic PID cascade
+    from models.Analytic.AttitudeController import AttittudeController
+    from models.Analytic.PositionController import PositionController
+    nd, T = 6, 12
+    masses = rng.uniform(1.3, 1.9, nd)
+    forces = rng.uniform(6, 8, nd)
+    attc, posc = AttittudeController(nd, masses, forces), PositionController(nd)
+    pid_ref = np.array([0.4, -0.3, 10.0, 0.6])
+    xyz_seq = pid_ref[:3, None, None] + rng.normal(scale=1.2, size=(3, T, nd))
+    xyz_seq[:, 3] += 4.0                                   # exercises the +-2 error clip and the output clips
+    rpy_seq = rng.uniform(-0.6, 0.6, size=(3, T, nd))
+    rpy_seq[2] = rng.uniform(-np.pi, np.pi, size=(T, nd))
+    pos_out, rpyz_out, ctrl_out = [], [], []
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        for t in range(T):
+            pa = posc.compute_control(pid_ref[:3], xyz_seq[:, t])
+            rz = attc.tilts2rpy(pa, np.ones(nd) * pid_ref[3])
+            ct = attc.compute_control(rz, rpy_seq[:, t])
+            pos_out.append(np.array(pa)); rpyz_out.append(np.array(rz)); ctrl_out.append(np.array(ct))
+    out["pid_masses"], out["pid_forces"], out["pid_ref"] = masses, forces, pid_ref
+    out["pid_xyz"], out["pid_rpy"] = xyz_seq, rpy_seq
+    out["pid_pos_action"], out["pid_rpyz"], out["pid_ctrl"] = np.array(pos_out), np.array(rpyz_out), np.array(ctrl_out)
+
     # ------------------------------------------------------------------ a14
     cfg = {k: v for k, v in base.items() if not callable(v)}
     out["base_config_json"] = np.array(json.dumps(cfg))

@@ -120,3 +120,31 @@ double twin_reward_q(int kind, const double* qpos, const double* qvel, const dou
   return reward<double>(kind, sv, a, k, ref, max_distance, &Rq);
 }
 }
+
+// ---- qd_pid.h (the analytic PID cascade) on the host, float64 and float32 ----
+#include "qd_pid.h"
+template <class T>
+static void run_pid(double* st13, const double* ref, const double* xyz, const double* rpy, double mass, double force,
+                    double* pos_action, double* rpyz, double* ctrl, double* action) {
+  PidState<T> c;
+  for (int k = 0; k < 3; k++) { c.pos_i[k] = st13[k]; c.pos_prev[k] = st13[3 + k]; c.att_i[k] = st13[6 + k]; c.att_prev[k] = st13[9 + k]; }
+  c.first = (uint32_t)st13[12];
+  T r4[4] = {(T)ref[0], (T)ref[1], (T)ref[2], (T)ref[3]}, p[3] = {(T)xyz[0], (T)xyz[1], (T)xyz[2]}, a[3] = {(T)rpy[0], (T)rpy[1], (T)rpy[2]};
+  T pa[3], rz[4], ct[4];
+  pid_position(c, r4, p, pa);
+  pid_tilts2rpy(pa, r4[3], rz);
+  pid_attitude(c, rz, a, (T)mass, frcp((T)force), ct);
+  for (int k = 0; k < 3; k++) { pos_action[k] = pa[k]; st13[k] = c.pos_i[k]; st13[3 + k] = c.pos_prev[k]; st13[6 + k] = c.att_i[k]; st13[9 + k] = c.att_prev[k]; }
+  st13[12] = c.first;
+  for (int k = 0; k < 4; k++) { rpyz[k] = rz[k]; ctrl[k] = ct[k]; action[k] = qclamp(ct[k] - T(0.1), T(0), T(1)); }
+}
+extern "C" {
+void twin_pid_f64(double* st13, const double* ref, const double* xyz, const double* rpy, double mass, double force,
+                  double* pos_action, double* rpyz, double* ctrl, double* action) {
+  run_pid<double>(st13, ref, xyz, rpy, mass, force, pos_action, rpyz, ctrl, action);
+}
+void twin_pid_f32(double* st13, const double* ref, const double* xyz, const double* rpy, double mass, double force,
+                  double* pos_action, double* rpyz, double* ctrl, double* action) {
+  run_pid<float>(st13, ref, xyz, rpy, mass, force, pos_action, rpyz, ctrl, action);
+}
+}

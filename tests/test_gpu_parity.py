@@ -646,3 +646,140 @@ def test_simple_drone_multi_drone_reset_placement(qd):
     assert abs(rew - (0.1 - np.linalg.norm(ob2[:3] - [0, 0, 1]))) < 1e-5            # drone 0 only
     ob3 = env.reset()                                                                # a new episode draws new noise
     assert not np.allclose(ob3[6:], ob[6:])
+
+
+# ------------------------------------------------------------------ analytic PID cascade on the device
+def _pid_planes(env):
+    """controller memory planes C0..C3 of the arena (csrc/qd_kernels.hip: groups 22..25) -> [n, 16] float32"""
+    npad = (env.n + 255) // 256 * 256
+    g = env.arena[:26 * npad * 16].view(torch.float32).view(26, npad, 4)[22:26, :env.n]
+    return g.permute(1, 0, 2).reshape(env.n, 16).cpu().numpy()
+
+
+def _mild_state(rng, n, load, z=10.0):
+    nq, nv = (9, 8) if load else (7, 6)
+    qpos = np.zeros((n, nq)); qpos[:, :3] = np.array([0, 0, z]) + rng.normal(scale=0.25, size=(n, 3)); qpos[:, 3] = 1
+    if load:
+        qpos[:, 7:] = rng.normal(scale=0.05, size=(n, 2))
+    qvel = rng.normal(scale=0.1, size=(n, nv))
+    return qpos, qvel
+
+
+@pytest.mark.parametrize("load", [True, False])
+def test_pid_action_vs_reference_controllers(qd, orc, load):
+    """qd_pid_action against the oracle's restatement of PositionController / AttittudeController (itself pinned by the
+    reference's outputs, tests/golden pid_*), fed with the device's own state vectors, over 40 closed-loop steps:
+    first-step derivative suppression, integrators and the clips all take part."""
+    rng = np.random.default_rng(31)
+    n, L = 192, qd._lib
+    ref = (0.2, -0.1, 10.0, 0.3)
+    raw = rand_raw(rng, n, load)
+    qpos, qvel = _mild_state(rng, n, load)
+    qpos[:8, :3] += 3.0                                   # beyond the +-2 error clip, saturated outputs
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs="BaseDroneEnv", ref=ref, max_steps=10 ** 6, max_distance=1e9))
+    env.set_params(raw)
+    env.set_state(qpos, qvel, np.zeros((n, 4)))
+    pid = orc.Pid(raw[:, 0] + raw[:, 5] + 0.2 * raw[:, 4], raw[:, 2])
+    st = _pid_planes(env)
+    assert np.all(st[:, :3] == 0) and np.all(st[:, 3].view(np.uint32) == 3)   # fresh controller objects after qd_init
+    worst = 0.0
+    for t in range(40):
+        s = env.drone_states().cpu().numpy().astype(np.float64)
+        want = pid.action(ref, s[:, :3], s[:, 3:6])
+        got = env.pid_action()
+        worst = max(worst, float(np.abs(got.cpu().numpy() - want).max()))
+        env.step(got)
+    print("pid action worst abs error", worst)
+    assert worst < 2e-4
+    st = _pid_planes(env)
+    assert np.all(st[:, 3].view(np.uint32) == 0)
+    want_i = np.array([[c.pos_i[0], c.pos_i[1], c.pos_i[2]] for c in pid.c])
+    np.testing.assert_allclose(st[:, :3], want_i, atol=1e-4)
+    # qd_pid_reset(mask): new controller objects for the selected envs only
+    mask = torch.zeros(n, dtype=torch.uint8, device="cuda"); mask[::2] = 1
+    env.pid_reset(mask)
+    st2 = _pid_planes(env)
+    assert np.all(st2[::2, :3] == 0) and np.all(st2[::2, 3].view(np.uint32) == 3)
+    np.testing.assert_array_equal(st2[1::2], st[1::2])
+
+
+def test_rollout_pid_equals_action_plus_step(qd):
+    """one launch of qd_rollout_pid == T x (qd_pid_action, qd_step), including the actions it reports"""
+    rng = np.random.default_rng(8)
+    n, L, T = 300, qd._lib, 60
+    raw = rand_raw(rng, n, True)
+    qpos, qvel = _mild_state(rng, n, True, z=15.0)
+    envs = []
+    for _ in range(2):
+        e = qd.dev.DeviceEnv(make_cfg(L, n, load=True, max_steps=10 ** 6))
+        e.set_params(raw); e.set_state(qpos, qvel, np.zeros((n, 4)))
+        envs.append(e)
+    ob, rw, tr, ac = envs[0].rollout_pid(T, want_actions=True)
+    for t in range(T):
+        a = envs[1].pid_action()
+        o, r, tt = envs[1].step(a)
+        np.testing.assert_allclose(ac[t].cpu().numpy(), a.cpu().numpy(), atol=2e-4)
+        np.testing.assert_allclose(ob[t].cpu().numpy(), o.cpu().numpy(), atol=2e-4)
+        np.testing.assert_allclose(rw[t].cpu().numpy(), r.cpu().numpy(), atol=2e-4)
+        assert torch.equal(tr[t], tt)
+    np.testing.assert_allclose(_pid_planes(envs[0]), _pid_planes(envs[1]), atol=2e-4)
+    ob2, rw2, tr2 = envs[0].rollout_pid(3)                # actions_out is optional
+    assert ob2.shape == (3, n, envs[0].D)
+
+
+@pytest.mark.parametrize("load", [True, False])
+def test_pid_closed_loop_vs_oracle(qd, orc, load):
+    """attitude_test.py's loop (controller -> vector_step) for 400 steps: the device runs it inside ONE kernel launch,
+    the float64 oracle runs it step by step on the CPU, each on its own state.  The reference's cascade is only
+    lightly damped (and sinks ~1.5 m below the reference: its thrust feed-forward goes through clip(ctrl - 0.1) and
+    then the env's 0.1 + 0.9 a map), so the comparison stays in its well-behaved regime: small initial offsets."""
+    rng = np.random.default_rng(17)
+    n, L, T = 128, qd._lib, 400
+    ref = (0.0, 0.0, 10.0, 0.0)
+    raw = rand_raw(rng, n, load)
+    qpos, qvel = _mild_state(rng, n, load)
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs="BaseDroneEnv", ref=ref, max_steps=10 ** 6, max_distance=1e9))
+    env.set_params(raw)
+    env.set_state(qpos, qvel, np.zeros((n, 4)))
+    ob = orc.Batch(raw, load, 0, L.REWARD_KINDS.index("distance_energy_reward"), 0.01, 1, 1, ref, 1e9, 10 ** 6)
+    ob.qpos[:], ob.qvel[:] = qpos.astype(np.float32), qvel.astype(np.float32)
+    pid = orc.Pid(raw[:, 0] + raw[:, 5] + 0.2 * raw[:, 4], raw[:, 2])
+    so = np.array([orc.drone_state(int(load), ob.qpos[i], ob.qvel[i], ob.sensor[i], ob.act[i], ref, raw[i]) for i in range(n)])
+    og, rg, tg, ag = env.rollout_pid(T, want_actions=True)
+    og, ag = og.cpu().numpy().astype(np.float64), ag.cpu().numpy().astype(np.float64)
+    worst = 0.0
+    for t in range(T):
+        a = pid.action(ref, so[:, :3], so[:, 3:6])
+        oo, ro, to = ob.step(a, threads=8)
+        so = oo.copy()
+        if t % 50 == 49:
+            k = 12 + (2 if load else 0)
+            err = np.max(np.abs(og[t][:, :k] - so[:, :k]) / np.maximum(1.0, np.abs(so[:, :k])))
+            worst = max(worst, float(err))
+    print("PID closed loop (load=%s): worst relative state error %.3e, final |xy| max %.3f, z range %.2f..%.2f"
+          % (load, worst, np.abs(so[:, :2]).max(), so[:, 2].min(), so[:, 2].max()))
+    assert worst < 1e-3
+    if not load:  # without the load the cascade is stable; with it the swing mode grows slowly in BOTH systems alike
+        assert np.abs(og[-1][:, :2]).max() < 1.5 and og[-1][:, 2].min() > 6.0
+    np.testing.assert_allclose(ag[-1], a, atol=2e-3)
+
+
+def test_rollout_pid_auto_reset_and_errors(qd):
+    """an env truncated and re-sampled inside qd_rollout_pid starts its new episode with fresh controller objects;
+    SimpleDrone configurations are refused"""
+    n, L = 256, qd._lib
+    env = qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, auto_reset=1, max_steps=7, seed=5))
+    env.reset()
+    ob, rw, tr = env.rollout_pid(21)
+    assert torch.all(tr[6] == 1) and torch.all(tr[13] == 1) and torch.all(tr[20] == 1) and int(tr.sum()) == 3 * n
+    st = _pid_planes(env)
+    assert np.all(st[:, 3].view(np.uint32) == 3) and np.all(st[:, :3] == 0)   # reset at the last step's truncation
+    env.rollout_pid(3)
+    st = _pid_planes(env)
+    assert np.all(st[:, 3].view(np.uint32) == 0) and np.abs(st[:, 4:7]).max() > 0
+    simple = qd.dev.DeviceEnv(make_cfg(L, 4, load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, ctrl_map=0, term=1,
+                                       start=2, start_pos=(0, 0, 1, 0), ref=(0, 0, 1, 0)))
+    with pytest.raises(NotImplementedError):
+        simple.rollout_pid(2)
+    with pytest.raises(NotImplementedError):
+        simple.pid_action()

@@ -169,3 +169,24 @@ def test_quaternion_matrix_fast_path_equals_rpy_path(twin, orc):
         for kind in range(17):
             got = twin.twin_reward_q(kind, P(qpos), P(qvel), P(sens), P(act), P(ref), P(par), P(a), 37, C.c_double(4.0))
             assert abs(got - orc.reward(kind, s, a, 37, ref, 4.0)) < 1e-9, kind
+
+
+@pytest.mark.parametrize("prec,tol", [("f64", 1e-11), ("f32", 2e-5)])
+def test_pid_header_vs_reference_controllers(twin, golden, prec, tol):
+    """csrc/qd_pid.h (what the GPU runs) against the reference's PositionController / AttittudeController outputs."""
+    G = golden
+    fn = getattr(twin, "twin_pid_" + prec)
+    nd, T = len(G["pid_masses"]), G["pid_xyz"].shape[1]
+    ref = np.ascontiguousarray(G["pid_ref"])
+    for d in range(nd):
+        st = np.zeros(13); st[12] = 3
+        for t in range(T):
+            xyz = np.ascontiguousarray(G["pid_xyz"][:, t, d]); rpy = np.ascontiguousarray(G["pid_rpy"][:, t, d])
+            pa, rz, ct, ac = np.zeros(3), np.zeros(4), np.zeros(4), np.zeros(4)
+            fn(P(st), P(ref), P(xyz), P(rpy), C.c_double(G["pid_masses"][d]), C.c_double(G["pid_forces"][d]),
+               P(pa), P(rz), P(ct), P(ac))
+            np.testing.assert_allclose(pa, G["pid_pos_action"][t][:, d], rtol=0, atol=tol * 50)  # D gain * 50 Hz
+            np.testing.assert_allclose(rz, G["pid_rpyz"][t][:, d], rtol=0, atol=tol * 50)
+            np.testing.assert_allclose(ct, G["pid_ctrl"][t][d], rtol=0, atol=tol * 50)
+            np.testing.assert_allclose(ac, np.clip(G["pid_ctrl"][t][d] - 0.1, 0, 1), rtol=0, atol=tol * 50)
+        assert st[12] == 0

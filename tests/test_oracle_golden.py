@@ -159,3 +159,25 @@ def test_philox_known_answers(orc):
     assert orc.philox4x32([0xffffffff] * 4, [0xffffffff] * 2) == [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]
     assert orc.philox4x32([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0]) == \
         [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1]
+
+
+# ---------------------------------------------------------------- 8f-3: analytic PID cascade
+def test_pid_cascade_matches_reference_controllers(golden, orc):
+    G, oracle = golden, orc
+    """models/Analytic/PositionController.py + AttitudeController.py over a 12-step sequence with state
+    (first-step derivative suppression, integrators, error / output clips, the non-orthonormal Rd)."""
+    pid = oracle.Pid(G["pid_masses"], G["pid_forces"])
+    ref = G["pid_ref"]
+    T = G["pid_xyz"].shape[1]
+    for t in range(T):
+        pa = pid.position(ref[:3], G["pid_xyz"][:, t].T)
+        np.testing.assert_allclose(pa.T, G["pid_pos_action"][t], rtol=0, atol=1e-12)
+        rz = oracle.Pid.tilts2rpy(pa, ref[3])
+        np.testing.assert_allclose(rz.T, G["pid_rpyz"][t], rtol=0, atol=1e-12)
+        ct = pid.attitude(rz, G["pid_rpy"][:, t].T)
+        np.testing.assert_allclose(ct, G["pid_ctrl"][t], rtol=0, atol=1e-12)
+    # the fused entry point gives clip(ctrl - 0.1, 0, 1) of the same sequence
+    pid2 = oracle.Pid(G["pid_masses"], G["pid_forces"])
+    for t in range(T):
+        a = pid2.action(ref, G["pid_xyz"][:, t].T, G["pid_rpy"][:, t].T)
+        np.testing.assert_allclose(a, np.clip(G["pid_ctrl"][t] - 0.1, 0, 1), rtol=0, atol=1e-12)
