@@ -351,6 +351,14 @@ def main():
                         e3._dev.rollout(a3)
                     torch.cuda.synchronize()
                     extras["rollout_kernel_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
+                    # closed loop with the on-device analytic PID cascade as the action source (attitude_test.py's loop)
+                    e3._dev.rollout_pid(256)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    for _ in range(8):
+                        e3._dev.rollout_pid(256)
+                    torch.cuda.synchronize()
+                    extras["pid_closed_loop_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
                 other = "config2" if args.config != "config2" else "config3"
                 e4, alg4 = make_env(other, n, 5, device)
                 (e4.vector_reset_tensor() if other == "config3" else e4.reset())
