@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QD_VERSION 1
+#define QD_VERSION 2
 
 typedef struct qd_env qd_env;
 
@@ -54,7 +54,7 @@ enum { QD_START_FIXED = 0,  /* random_start_pos = False   (BaseDroneEnv.py:245-2
        QD_START_RANDOM = 1, /* random_start_pos = True    (BaseDroneEnv.py:220-244) */
        QD_START_SIMPLE = 2  /* SimpleDrone.reset_model    (SimpleDrone.py:63-72)    */ };
 
-enum { QD_REF_STATIC = 0, QD_REF_CIRCLE = 1 };
+enum { QD_REF_STATIC = 0, QD_REF_CIRCLE = 1, QD_REF_STEP = 2, QD_REF_RAMP = 3 };
 
 /* observation variants: BaseDroneEnv._get_obs and the classes of observation_wrappers.py, in file order */
 enum {
@@ -99,9 +99,16 @@ typedef struct qd_config {
    * QD_REF_CIRCLE: gen_circle_trajectory (evaluation.py:135-138) around `reference`, phase-shifted per env:
    *   ref_i(k) = reference + (r cos(2 pi f k dt + 2 pi i/N), r sin(...), 0, 0),  k = the env's episode step,
    *   dt = frame_skip * timestep; the step taken from episode step k is rewarded against ref_i(k). */
-  int32_t  ref_mode;            /* QD_REF_STATIC / QD_REF_CIRCLE */
+  int32_t  ref_mode;            /* QD_REF_* */
   int32_t  reserved0;
   double   ref_radius, ref_frequency;
+  /* QD_REF_STEP / QD_REF_RAMP: gen_step_trajectory / gen_ramp_trajectory (evaluation.py:141-152) with
+   * start_pos = `reference`, end_pos = ref_end, sampled once per env step at t_k = k dt like the reference's
+   * t = arange(0, duration, 0.01):  step: t_k < ref_t0 ? reference : ref_end;
+   * ramp: t_k < ref_t0 ? reference : reference + (t_k - ref_t0)/(ref_duration - ref_t0) (ref_end - reference);
+   * beyond the last sample (k >= ceil(ref_duration/dt)) the last waypoint is held (extension). */
+  double   ref_t0, ref_duration;
+  double   ref_end[4];
 } qd_config;
 
 const char* qd_last_error(void);

@@ -13,7 +13,7 @@ MODEL_NOLOAD, MODEL_LOAD = 0, 1
 CTRL_DIRECT, CTRL_AFFINE = 0, 1
 TERM_DEFAULT, TERM_SIMPLE = 0, 1
 START_FIXED, START_RANDOM, START_SIMPLE = 0, 1, 2
-REF_STATIC, REF_CIRCLE = 0, 1
+REF_STATIC, REF_CIRCLE, REF_STEP, REF_RAMP = 0, 1, 2, 3
 TF_QUAT2RPY, TF_RPY2QUAT, TF_QUAT2DCM, TF_DCM2QUAT, TF_PENDRP2QUAT = range(5)
 
 # observation variants, in the order of include/qd.h (= file order of observation_wrappers.py)
@@ -46,6 +46,7 @@ class QdConfig(C.Structure):
         ("param_center", C.c_double * 6), ("param_width", C.c_double * 6), ("param_difficulty", C.c_double),
         ("seed", C.c_uint64),
         ("ref_mode", C.c_int32), ("reserved0", C.c_int32), ("ref_radius", C.c_double), ("ref_frequency", C.c_double),
+        ("ref_t0", C.c_double), ("ref_duration", C.c_double), ("ref_end", C.c_double * 4),
     ]
 
 

@@ -57,6 +57,8 @@ struct KArgs {
   int main_blocks;    // workgroups [0, main_blocks) step envs; [main_blocks, 2*main_blocks) are samplers
   int ref_mode;       // QD_REF_CIRCLE: the reference is a function of (env, episode step), see moving_reference()
   float ref_radius, ref_omega_dt, ref_phase_step;  // radius, 2 pi f dt, 2 pi / N
+  int ref_k0, ref_kmax;                            // QD_REF_STEP / RAMP: first sample with t_k >= t0; last sample index
+  float ref_dt, ref_t0, ref_inv_span, ref_end[4];  // ramp: (k dt - t0) / (duration - t0)
   unsigned long long seed;
   SampleCfg sc;
 };
@@ -101,14 +103,23 @@ template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
   return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : spec_runtime<SPEC>() ? a.ctrl_map : (int)QD_CTRL_AFFINE;
 }
 
-// gen_circle_trajectory (evaluation.py:135-138) around the configured reference, one phase per env
+// the waypoint generators of evaluation.py:135-152 evaluated in the kernel, k = the env's episode step:
+// circle around the configured reference (one phase per env), step and ramp from the reference to ref_end
 __device__ __forceinline__ void moving_reference(const KArgs& a, int i, int k, float ref[4]) {
-  float sn, cs;
-  qsincos(a.ref_omega_dt * (float)k + a.ref_phase_step * (float)i, &sn, &cs);
-  ref[0] = a.ref[0] + a.ref_radius * cs;
-  ref[1] = a.ref[1] + a.ref_radius * sn;
-  ref[2] = a.ref[2];
-  ref[3] = a.ref[3];
+  if (a.ref_mode == QD_REF_CIRCLE) {
+    float sn, cs;
+    qsincos(a.ref_omega_dt * (float)k + a.ref_phase_step * (float)i, &sn, &cs);
+    ref[0] = a.ref[0] + a.ref_radius * cs;
+    ref[1] = a.ref[1] + a.ref_radius * sn;
+    ref[2] = a.ref[2];
+    ref[3] = a.ref[3];
+  } else {
+    const int kk = min(k, a.ref_kmax);
+    float w = 0.f;
+    if (kk >= a.ref_k0) w = a.ref_mode == QD_REF_STEP ? 1.f : ((float)kk * a.ref_dt - a.ref_t0) * a.ref_inv_span;
+#pragma unroll
+    for (int c = 0; c < 4; c++) ref[c] = a.ref_mode == QD_REF_STEP && w == 1.f ? a.ref_end[c] : a.ref[c] + w * (a.ref_end[c] - a.ref[c]);
+  }
 }
 
 // WITH_ACC = false: the stored accelerometer reading is not fetched (the step kernels overwrite it).
@@ -156,7 +167,7 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
     }
   }
   e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
-  if (a.ref_mode == QD_REF_CIRCLE) {
+  if (a.ref_mode != QD_REF_STATIC) {
     moving_reference(a, i, e.num_steps, e.ref);
   } else if (a.per_env_ref) {
     const float4 r = g[G_REF * np + i];
@@ -394,7 +405,7 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   }
   if (a.auto_reset && tr) {
     reset_in_step<LOAD>(a, i, e);
-    if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, 0, e.ref);
+    if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, e.ref);
     if (term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
   *rew = r;
@@ -476,7 +487,7 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
       const float4 action = next_action;
       // software pipelining: the next step's action is in flight while this step computes
       if (t + 1 < T) next_action = reinterpret_cast<const float4*>(actions)[(size_t)(t + 1) * a.n + i];
-      if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, e.num_steps, e.ref);
+      if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, e.num_steps, e.ref);
       float r;
       uint8_t tr;
       env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &tr);
@@ -554,7 +565,7 @@ __global__ __launch_bounds__(64) void k_rollout_pid(KArgs a, int T, float* __res
   }
   for (int t = 0; t < T; t++) {
     if (live) {
-      if (a.ref_mode == QD_REF_CIRCLE) moving_reference(a, i, e.num_steps, e.ref);
+      if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, e.num_steps, e.ref);
       const float4 action = pid_env_action(c, e);
       if (actions_out) reinterpret_cast<float4*>(actions_out)[(size_t)t * a.n + i] = action;
       float r;
@@ -951,7 +962,25 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
   // sampler workgroups pay off while the launch is a latency chain (few waves, idle CUs); with >= 65536 envs the
   // chip is full and a second set of workgroups only adds traffic, so truncated lanes sample inline there
-  if (c->ref_mode != QD_REF_STATIC && c->ref_mode != QD_REF_CIRCLE) { delete e; return fail(QD_ERR_INVALID, "unknown ref_mode %d", c->ref_mode); }
+  if (c->ref_mode < QD_REF_STATIC || c->ref_mode > QD_REF_RAMP) { delete e; return fail(QD_ERR_INVALID, "unknown ref_mode %d", c->ref_mode); }
+  k.ref_k0 = 0; k.ref_kmax = 0; k.ref_dt = k.ref_t0 = k.ref_inv_span = 0.f;
+  for (int i = 0; i < 4; i++) k.ref_end[i] = (float)c->ref_end[i];
+  if (c->ref_mode == QD_REF_STEP || c->ref_mode == QD_REF_RAMP) {
+    const double dt = c->timestep * c->frame_skip, t0 = c->ref_t0, dur = c->ref_duration;
+    if (!(dur > 0.0) || !(t0 >= 0.0) || (c->ref_mode == QD_REF_RAMP && !(dur > t0)) || dur / dt > 1e9) {
+      delete e;
+      return fail(QD_ERR_INVALID, "step / ramp reference needs 0 <= ref_t0 (< ref_duration for a ramp), ref_duration > 0");
+    }
+    // the comparisons numpy makes on t = arange(0, duration, dt): t_k = k * dt in float64
+    long long k0 = (long long)ceil(t0 / dt);
+    while (k0 > 0 && (double)(k0 - 1) * dt >= t0) k0--;
+    while ((double)k0 * dt < t0) k0++;
+    const long long len = (long long)ceil(dur / dt);
+    k.ref_k0 = (int)(k0 < 2000000000LL ? k0 : 2000000000LL);
+    k.ref_kmax = (int)(len > 0 ? len - 1 : 0);
+    k.ref_dt = (float)dt; k.ref_t0 = (float)t0;
+    k.ref_inv_span = c->ref_mode == QD_REF_RAMP ? (float)(1.0 / (dur - t0)) : 0.f;
+  }
   k.ref_mode = c->ref_mode;
   k.ref_radius = (float)c->ref_radius;
   k.ref_omega_dt = (float)(6.283185307179586 * c->ref_frequency * c->timestep * c->frame_skip);

@@ -199,11 +199,22 @@ class BaseDroneEnv(_VectorEnvBase):
         c.param_difficulty = float(self.param_difficulty)
         c.seed = self.seed_value & 0xFFFFFFFFFFFFFFFF
         if self.reference_trajectory:
-            if self.reference_trajectory.get('type') != 'circle':
-                raise ValueError("reference_trajectory type must be 'circle'")
-            c.ref_mode = L.REF_CIRCLE
-            c.ref_radius = float(self.reference_trajectory.get('radius', 1.0))
-            c.ref_frequency = float(self.reference_trajectory.get('frequency', 0.5))
+            tr = self.reference_trajectory
+            kind = tr.get('type')
+            if kind == 'circle':      # gen_circle_trajectory (evaluation.py:135-138) around `reference`
+                c.ref_mode = L.REF_CIRCLE
+                c.ref_radius = float(tr.get('radius', 1.0))
+                c.ref_frequency = float(tr.get('frequency', 0.5))
+            elif kind in ('step', 'ramp'):   # gen_step_trajectory / gen_ramp_trajectory (evaluation.py:141-152)
+                c.ref_mode = L.REF_STEP if kind == 'step' else L.REF_RAMP
+                c.ref_t0 = float(tr.get('step_time' if kind == 'step' else 'start_time', 5.0))
+                c.ref_duration = float(tr.get('duration', 10.0))
+                end = [float(x) for x in tr.get('end_pos', [0, 0, 1, 0])]
+                if len(end) != 4:
+                    raise ValueError("reference_trajectory end_pos must be (x, y, z, yaw)")
+                c.ref_end[:] = end
+            else:
+                raise ValueError("reference_trajectory type must be 'circle', 'step' or 'ramp'")
         return c
 
     # ----------------------------------------------------------------------- attributes

@@ -276,6 +276,17 @@ def gen_params_philox(seed, env, regen, center, width, difficulty, random_params
     return raw
 
 
+def trajectory(mode, p, start, end, dt, n):
+    """first n samples of gen_{circle,step,ramp}_trajectory (evaluation.py:135-152); mode 1 / 2 / 3"""
+    pp = np.zeros(4); pp[:len(p)] = p
+    start, end, out = _f64(start), _f64(end), np.zeros((n, 4))
+    f = lib().orc_trajectory_point
+    f.restype = None
+    for k in range(n):
+        f(int(mode), _p(pp), _p(start), _p(end), C.c_double(dt), C.c_long(k), _p(out[k]))
+    return out
+
+
 class OrcPid(C.Structure):
     _fields_ = [("pos_i", C.c_double * 3), ("pos_prev", C.c_double * 3), ("att_i", C.c_double * 3),
                 ("att_prev", C.c_double * 3), ("pos_first", C.c_int), ("att_first", C.c_int)]

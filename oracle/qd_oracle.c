@@ -1118,3 +1118,17 @@ void orc_pid_action(OrcPid *c, const double ref[4], const double xyz[3], const d
   orc_pid_attitude(c, rpyz, rpy, mass, motor_force, action);
   for (int m = 0; m < 4; m++) action[m] = clip3(action[m] - 0.1, 0, 1);
 }
+
+/* ------------------------------------------------ waypoint generators (8f-4) */
+void orc_trajectory_point(int mode, const double p[4], const double start[4], const double end[4], double dt, long k,
+                          double out[4]) {
+  const double t = (double)k * dt; /* numpy arange: start + k * step */
+  if (mode == 1) {                 /* evaluation.py:135-138 */
+    out[0] = p[1] * cos(2 * PI * p[0] * t); out[1] = p[1] * sin(2 * PI * p[0] * t); out[2] = p[2]; out[3] = 0;
+  } else if (mode == 2) {          /* evaluation.py:141-144 */
+    for (int c = 0; c < 4; c++) out[c] = t < p[0] ? start[c] : end[c];
+  } else {                         /* evaluation.py:147-152 */
+    for (int c = 0; c < 4; c++)
+      out[c] = t < p[0] ? start[c] : start[c] + (t - p[0]) / (p[1] - p[0]) * (end[c] - start[c]);
+  }
+}

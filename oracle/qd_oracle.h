@@ -181,6 +181,13 @@ void orc_pid_attitude(OrcPid *c, const double rpyz[4], const double rpy[3], doub
 void orc_pid_action(OrcPid *c, const double ref[4], const double xyz[3], const double rpy[3], double mass,
                     double motor_force, double action[4]);
 
+/* ---- waypoint generators of evaluation.py:135-152, sample k of t = arange(0, T, dt).
+ * mode 1 circle: p = {f, r, h, -}: (r cos(2 pi f t), r sin(2 pi f t), h, 0)
+ * mode 2 step  : p = {step_time}:  t < step_time ? start : end
+ * mode 3 ramp  : p = {start_time, duration}: t < start_time ? start : start + (t-start_time)/(duration-start_time) (end-start) */
+void orc_trajectory_point(int mode, const double p[4], const double start[4], const double end[4], double dt, long k,
+                          double out[4]);
+
 #ifdef __cplusplus
 }
 #endif

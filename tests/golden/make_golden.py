@@ -340,6 +340,26 @@ def main():
     out["pid_xyz"], out["pid_rpy"] = xyz_seq, rpy_seq
     out["pid_pos_action"], out["pid_rpyz"], out["pid_ctrl"] = np.array(pos_out), np.array(rpyz_out), np.array(ctrl_out)
 
+    # ------------------------------------------------------------------ 8f-4: trajectory generators
+    # evaluation.py cannot be imported (ray, matplotlib, the policy models at module scope); its three pure
+    # generator functions are compiled from the file where it lies and executed on their own.
+    import ast
+    with open(os.path.join(REF, "evaluation.py")) as fh:
+        tree = ast.parse(fh.read())
+    wanted = ("gen_circle_trajectory", "gen_step_trajectory", "gen_ramp_trajectory")
+    mod = ast.Module(body=[n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in wanted], type_ignores=[])
+    ns = {"np": np}
+    exec(compile(mod, os.path.join(REF, "evaluation.py"), "exec"), ns)
+    out["traj_circle_args"] = np.array([2.0, 0.5, 1.0, 15.0])          # T, f, r, h
+    out["traj_circle"] = ns["gen_circle_trajectory"](T=2.0, f=0.5, r=1.0, h=15.0)[1]
+    out["traj_start"], out["traj_end"] = np.array([0.5, -0.5, 15.0, 0.0]), np.array([1.5, 0.25, 14.0, 0.6])
+    out["traj_step_args"] = np.array([0.57, 1.5])                       # step_time, duration
+    out["traj_step"] = ns["gen_step_trajectory"](0.57, 1.5, list(out["traj_start"]), list(out["traj_end"]))[1]
+    out["traj_ramp_args"] = np.array([0.4, 1.6])                        # start_time, duration
+    out["traj_ramp"] = ns["gen_ramp_trajectory"](0.4, 1.6, list(out["traj_start"]), list(out["traj_end"]))[1]
+    out["traj_step_default"] = ns["gen_step_trajectory"]()[1]
+    out["traj_ramp_default"] = ns["gen_ramp_trajectory"]()[1]
+
     # ------------------------------------------------------------------ a14
     cfg = {k: v for k, v in base.items() if not callable(v)}
     out["base_config_json"] = np.array(json.dumps(cfg))

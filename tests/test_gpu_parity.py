@@ -806,3 +806,32 @@ def test_attitude_test_script_shape(qd):
     env2.reset()
     ob2, _, _ = env2.rollout_pid_tensor(300)
     np.testing.assert_allclose(ob2[-1].cpu().numpy()[0][:12], st[:12], atol=5e-2)
+
+
+@pytest.mark.parametrize("kind", ["step", "ramp"])
+def test_step_and_ramp_waypoints_vs_reference_generators(qd, golden, kind):
+    """gen_step_trajectory / gen_ramp_trajectory (evaluation.py:141-152) evaluated inside the kernels: after k env steps
+    the reference entries of every env's state vector are the reference's k-th waypoint; past the end the last one holds."""
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameFullStateEnv
+    G = golden
+    want = G["traj_" + kind]
+    t0, dur = (G["traj_step_args"][0], G["traj_step_args"][1]) if kind == "step" else G["traj_ramp_args"]
+    tr = dict(type=kind, duration=float(dur), end_pos=list(G["traj_end"]))
+    tr["step_time" if kind == "step" else "start_time"] = float(t0)
+    cfg = dict(base_config, num_drones=96, reference=list(G["traj_start"]), start_pos=list(G["traj_start"]), random_start_pos=False,
+               random_params=False, max_steps=10 ** 6, max_distance=1e9, reference_trajectory=tr)
+    env = LocalFrameFullStateEnv(cfg)
+    env.vector_reset_tensor()
+    a = torch.full((96, 4), 0.45, device="cuda")
+    for k in range(len(want) + 5):
+        st = env._dev.drone_states().cpu().numpy()
+        np.testing.assert_allclose(st[:, 23:27], np.tile(want[min(k, len(want) - 1)], (96, 1)), atol=2e-6, err_msg="k=%d" % k)
+        env.vector_step_tensor(a)
+    # the one-launch rollout sees the same waypoints: its rewards equal the per-step path's
+    e1, e2 = LocalFrameFullStateEnv(cfg), LocalFrameFullStateEnv(cfg)
+    e1.vector_reset_tensor(); e2.vector_reset_tensor()
+    acts = torch.rand((80, 96, 4), device="cuda")
+    _, r1, _ = e1.rollout_tensor(acts)
+    r2 = torch.stack([e2.vector_step_tensor(acts[t])[1].clone() for t in range(80)])
+    np.testing.assert_allclose(r1.cpu().numpy(), r2.cpu().numpy(), atol=2e-4)

@@ -181,3 +181,17 @@ def test_pid_cascade_matches_reference_controllers(golden, orc):
     for t in range(T):
         a = pid2.action(ref, G["pid_xyz"][:, t].T, G["pid_rpy"][:, t].T)
         np.testing.assert_allclose(a, np.clip(G["pid_ctrl"][t] - 0.1, 0, 1), rtol=0, atol=1e-12)
+
+
+# ---------------------------------------------------------------- 8f-4: waypoint generators
+def test_trajectory_generators_match_reference(golden, orc):
+    """gen_circle_trajectory / gen_step_trajectory / gen_ramp_trajectory (evaluation.py:135-152)"""
+    G = golden
+    T, f, r, h = G["traj_circle_args"]
+    z = np.zeros(4)
+    np.testing.assert_allclose(orc.trajectory(1, [f, r, h], z, z, 0.01, len(G["traj_circle"])), G["traj_circle"], atol=1e-13)
+    s, e = G["traj_start"], G["traj_end"]
+    np.testing.assert_array_equal(orc.trajectory(2, [G["traj_step_args"][0]], s, e, 0.01, len(G["traj_step"])), G["traj_step"])
+    np.testing.assert_allclose(orc.trajectory(3, G["traj_ramp_args"], s, e, 0.01, len(G["traj_ramp"])), G["traj_ramp"], atol=1e-13)
+    np.testing.assert_array_equal(orc.trajectory(2, [5.0], [0, 0, 0, 0], [0, 0, 1, 0], 0.01, 1000), G["traj_step_default"])
+    np.testing.assert_allclose(orc.trajectory(3, [5.0, 10.0], [0, 0, 0, 0], [0, 0, 1, 0], 0.01, 1000), G["traj_ramp_default"], atol=1e-13)
