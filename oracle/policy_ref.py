@@ -1,0 +1,83 @@
+"""CPU float64 restatement of the reference's policy forward passes (actor + value, eval mode) and of its Beta
+action distribution.  TEST INFRASTRUCTURE ONLY, like the rest of oracle/: the product never imports it.
+
+Follows  models/PPO/RMA/RMA_model.py:77-110 (RMA_full.forward with train_adaptation=False, the train_PPO.py:39-45
+configuration), :262-292 (RMA_model.forward), models/PPO/SimpleMLP/SimpleMLP.py:72-98 (SimpleMLPmodel) and
+distributions.py:8-26 (MyBetaDist).  Pinned by tests/golden/policy_vectors.npz, which tests/golden/make_policy_golden.py
+produced by running those reference classes themselves (over functional stand-ins for ray's SlimFC / TorchModelV2,
+ray being absent: the vectors pin the reference's wiring, see that script's header).
+
+Weights are a dict keyed like the reference's checkpoints (`policy_state.pkl` -> 'weights'): SlimFC layers are
+`<seq>.<i>._model.0.weight/bias`, BatchNorm1d layers `<seq>.<i>.weight/bias/running_mean/running_var`.
+"""
+import numpy as np
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default
+
+
+def _fc(w, prefix, x, act):
+    y = x @ np.asarray(w[prefix + "._model.0.weight"], dtype=np.float64).T + np.asarray(w[prefix + "._model.0.bias"], dtype=np.float64)
+    return np.tanh(y) if act == "tanh" else y
+
+
+def _bn(w, prefix, x):
+    g, b = np.asarray(w[prefix + ".weight"], np.float64), np.asarray(w[prefix + ".bias"], np.float64)
+    m, v = np.asarray(w[prefix + ".running_mean"], np.float64), np.asarray(w[prefix + ".running_var"], np.float64)
+    return (x - m) / np.sqrt(v + BN_EPS) * g + b
+
+
+def _seq(w, name, x, acts):
+    """nn.Sequential `name` of SlimFC layers (act 'tanh' / None) and BatchNorm1d layers ('bn')"""
+    for i, a in enumerate(acts):
+        x = _bn(w, "%s.%d" % (name, i), x) if a == "bn" else _fc(w, "%s.%d" % (name, i), x, a)
+    return x
+
+
+def rma_full(w, obs, prev_actions, num_states=16, num_params=6):
+    """RMA_model.py:77-110 with train_adaptation=False: z = param_encoder(obs[:, -num_params:]),
+    features = hidden(cat(obs[:, :num_states], prev_actions, z)); returns (logits, value)"""
+    obs, prev = np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)
+    z = _seq(w, "param_encoder", obs[:, -num_params:], ["tanh", None])
+    feat = _seq(w, "_hidden_layers", np.concatenate([obs[:, :num_states], prev, z], axis=-1), ["tanh", "tanh", "bn"])
+    return _seq(w, "_logits", feat, ["tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]
+
+
+def rma_model(w, obs, prev_actions, num_states=16, num_params=6):
+    """RMA_model.py:262-292: the encoder ends in tanh here, four hidden layers, three logits layers"""
+    obs, prev = np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)
+    z = _seq(w, "param_encoder", obs[:, num_states:num_states + num_params], ["tanh", "tanh"])
+    feat = _seq(w, "_hidden_layers", np.concatenate([obs[:, :num_states], prev, z], axis=-1), ["tanh"] * 4 + ["bn"])
+    return _seq(w, "_logits", feat, ["tanh", "tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]
+
+
+def simple_mlp(w, obs, prev_actions):
+    """SimpleMLP.py:72-98: separate actor / critic trunks on cat(obs, prev_actions), BatchNorm on the input too"""
+    x = np.concatenate([np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)], axis=-1)
+    acts = ["bn"] + ["tanh"] * 4 + ["bn", "tanh", "tanh", None]
+    return _seq(w, "_logits", x, acts), _seq(w, "_value_branch", x, acts)[:, 0]
+
+
+FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp}
+
+
+def beta_params(logits):
+    """distributions.py:8-17: clamp to +-50, softplus + 1, first half = alpha (concentration1), second = beta"""
+    x = np.clip(np.asarray(logits, np.float64), -50, 50)
+    x = np.log(np.exp(x) + 1.0) + 1.0
+    h = x.shape[-1] // 2
+    return x[..., :h], x[..., h:]
+
+
+def beta_mean_action(logits):
+    """MyBetaDist.deterministic_sample (distributions.py:24-26): the Beta mean, no squashing"""
+    a, b = beta_params(logits)
+    return a / (a + b)
+
+
+def beta_logp(logits, x):
+    """MyBetaDist.logp (distributions.py:19-22): x clamped to [0.01, 0.99], summed over action dimensions"""
+    from scipy.special import gammaln
+    a, b = beta_params(logits)
+    x = np.clip(np.asarray(x, np.float64), 1e-2, 1 - 1e-2)
+    lp = (a - 1) * np.log(x) + (b - 1) * np.log1p(-x) - (gammaln(a) + gammaln(b) - gammaln(a + b))
+    return lp.sum(-1)

@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/policy_vectors.npz from the reference's own policy classes.
+
+Runs ONLY in the build container (needs /root/reference and torch); never on the GPU box.
+The reference's models (models/PPO/RMA/RMA_model.py: RMA_full, RMA_model; models/PPO/SimpleMLP/SimpleMLP.py:
+SimpleMLPmodel) and its action distribution (distributions.py: MyBetaDist) are imported from where they lie and
+run in eval mode on seeded inputs; weights, inputs and outputs are stored as data.
+
+ray is absent here.  Unlike the placeholders of make_golden.py, four of the ray names these files use carry
+behaviour the forward pass depends on, so they are replaced by FUNCTIONAL stand-ins written from ray's documented
+behaviour: SlimFC = nn.Linear followed by the named activation (state-dict keys `<x>._model.0.weight/bias`, the
+layout of the reference's checkpoints), normc_initializer, TorchModelV2.__init__ (stores its arguments),
+TorchDistributionWrapper.__init__ (stores inputs / model).  These vectors therefore pin the reference's WIRING
+(slicing, concatenation order, layer sizes, BatchNorm in eval mode, the Beta parameterisation), not ray's layers.
+Nothing from /root/reference is copied: the output holds numbers only.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+from torch import nn
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "policy_vectors.npz")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from make_golden import _install_placeholders  # noqa: E402
+
+
+def _install_ray_standins():
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class TorchModelV2:
+        def __init__(self, obs_space, action_space, num_outputs, model_config, name):
+            self.obs_space, self.action_space, self.num_outputs = obs_space, action_space, num_outputs
+            self.model_config, self.name = model_config, name
+            self.view_requirements = {}
+
+    def normc_initializer(std=1.0):
+        def init(tensor):
+            tensor.data.normal_(0, 1)
+            tensor.data *= std / torch.sqrt(tensor.data.pow(2).sum(1, keepdim=True))
+        return init
+
+    class SlimFC(nn.Module):
+        def __init__(self, in_size, out_size, initializer=None, activation_fn=None, use_bias=True, bias_init=0.0):
+            super().__init__()
+            linear = nn.Linear(in_size, out_size, bias=use_bias)
+            (initializer or nn.init.xavier_uniform_)(linear.weight)
+            if use_bias:
+                nn.init.constant_(linear.bias, bias_init)
+            layers = [linear]
+            if activation_fn == 'tanh':
+                layers.append(nn.Tanh())
+            elif activation_fn == 'relu':
+                layers.append(nn.ReLU())
+            elif activation_fn is not None and activation_fn != 'linear':
+                raise ValueError(activation_fn)
+            self._model = nn.Sequential(*layers)
+
+        def forward(self, x):
+            return self._model(x)
+
+    class AppendBiasLayer(nn.Module):
+        pass
+
+    class ViewRequirement:
+        def __init__(self, *a, **k):
+            self.args, self.kw = a, k
+
+    class SampleBatch(dict):
+        is_training = False
+
+    class TorchDistributionWrapper:
+        def __init__(self, inputs, model):
+            self.inputs, self.model = inputs, model
+
+    class TorchBeta(TorchDistributionWrapper):
+        pass
+
+    import typing
+    mod("ray.rllib.models"); mod("ray.rllib.models.torch")
+    mod("ray.rllib.models.torch.torch_modelv2", TorchModelV2=TorchModelV2)
+    mod("ray.rllib.models.torch.misc", SlimFC=SlimFC, AppendBiasLayer=AppendBiasLayer, normc_initializer=normc_initializer)
+    mod("ray.rllib.models.torch.torch_action_dist", TorchBeta=TorchBeta, TorchDistributionWrapper=TorchDistributionWrapper)
+    mod("ray.rllib.utils"); mod("ray.rllib.utils.annotations", override=lambda cls: (lambda f: f))
+    mod("ray.rllib.utils.framework", try_import_torch=lambda: (torch, nn))
+    mod("ray.rllib.utils.typing", Dict=typing.Dict, TensorType=typing.Any, List=typing.List, ModelConfigDict=dict)
+    mod("ray.rllib.policy"); mod("ray.rllib.policy.sample_batch", SampleBatch=SampleBatch)
+    mod("ray.rllib.policy.view_requirement", ViewRequirement=ViewRequirement)
+
+
+def _randomise(model, gen):
+    """trained-looking weights: non-zero biases, non-trivial BatchNorm statistics"""
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=gen) * 0.1)
+        for m in model.modules():
+            if isinstance(m, nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.num_features, generator=gen) * 0.2)
+                m.running_var.copy_(torch.rand(m.num_features, generator=gen) * 1.5 + 0.25)
+                m.weight.copy_(torch.rand(m.num_features, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.num_features, generator=gen) * 0.1)
+
+
+def main():
+    _install_placeholders()
+    _install_ray_standins()
+    sys.path.insert(0, REF)
+    import gymnasium
+    from models.PPO.RMA.RMA_model import RMA_full, RMA_model
+    from models.PPO.SimpleMLP.SimpleMLP import SimpleMLPmodel
+    from distributions import MyBetaDist
+
+    gen = torch.Generator().manual_seed(20250614)
+    n, D = 48, 22
+    obs_space = gymnasium.spaces.Box(low=-np.inf, high=np.inf, shape=(D,))
+    act_space = gymnasium.spaces.Box(low=0, high=1, shape=(4,))
+    cc = {'num_states': 16, 'num_params': 6, 'num_actions': 4, 'param_embed_dim': 8, 'train_adaptation': False,
+          'adapt_seq_len': 32}                                   # train_PPO.py:39-45
+    obs = torch.randn((n, D), generator=gen) * 1.5
+    obs[:, 16:] = torch.tensor([1, 0.17, 7, 0.01, 1.2, 0.3]) * (1 + 0.1 * torch.randn((n, 6), generator=gen))
+    prev = torch.rand((n, 4), generator=gen)
+    out = {"obs": obs.numpy(), "prev_actions": prev.numpy()}
+    for tag, cls in (("rma_full", RMA_full), ("rma_model", RMA_model), ("simple_mlp", SimpleMLPmodel)):
+        torch.manual_seed(7)
+        model = cls(obs_space, act_space, 8, {"custom_model_config": cc}, tag)
+        _randomise(model, gen)
+        model.eval()
+        if cls is RMA_full:
+            inp = {"obs_history": obs, "action_history": prev, "is_training": False}
+        else:
+            inp = {"obs": obs, "prev_actions": prev, "is_training": False}
+        with torch.no_grad():
+            logits, _ = model.forward(inp, [], None)
+            value = model.value_function()
+            dist = MyBetaDist(logits, model)
+            action = dist.deterministic_sample()
+            logp = dist.logp(action)
+        out[tag + "_logits"], out[tag + "_value"] = logits.numpy(), value.numpy()
+        out[tag + "_action"], out[tag + "_logp"] = action.numpy(), logp.numpy()
+        # the adaptation module is not on this path (train_adaptation=False, train_PPO.py:43): its weights stay out
+        sd = {k: v for k, v in model.state_dict().items() if not k.startswith("adaptation_module")}
+        out[tag + "_keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out[tag + "/" + k] = v.numpy()
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
+
+
+if __name__ == "__main__":
+    main()
