@@ -189,6 +189,51 @@ int qd_pid_action(qd_env* env, float* actions, void* stream);
 int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out,
                    void* stream);
 
+/* ---- on-device policy inference -----------------------------------------------
+ * The reference's actor / critic networks (models/PPO/RMA/RMA_model.py: RMA_full with
+ * train_adaptation=False, RMA_model; models/PPO/SimpleMLP/SimpleMLP.py: SimpleMLPmodel; eval mode)
+ * and its action distribution's deterministic sample (distributions.py:8-26, MyBetaDist) for a whole
+ * env batch in one launch, float32 on the matrix cores.  A policy is a short program over up to 4
+ * per-env activation buffers:
+ *   QD_POL_COPY_OBS  : buf[out_buf][out_off : +in_dim] = obs row [in_off : +in_dim]
+ *   QD_POL_COPY_PREV : same from the previous action (zeros where prev_truncated != 0 or no previous
+ *                      action exists: RLlib's ViewRequirement(shift=-1) at episode starts)
+ *   QD_POL_DENSE     : out slice = act(W in_slice + b), W float32 row-major [out_dim][in_dim] at
+ *                      weights[w_off], b at weights[b_off] (torch.nn.Linear layout)
+ *   QD_POL_AFFINE    : out slice = out slice * weights[w_off + c] + weights[b_off + c]
+ *                      (eval-mode BatchNorm1d: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
+ * Outputs: logits[N, n_logits] (n_logits = 2 * act_dim), value[N] (if the program has a value slot) and
+ * actions[N, act_dim] = alpha / (alpha + beta) with (alpha, beta) = softplus(clamp(logits, +-50)) + 1.
+ * The caller owns the device buffer the packed weights live in (qd_policy_packed_bytes). */
+enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3 };
+enum { QD_ACT_NONE = 0, QD_ACT_TANH = 1, QD_ACT_RELU = 2 };
+typedef struct qd_policy qd_policy;
+typedef struct qd_policy_op {
+  int32_t kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act;
+  int64_t w_off, b_off;         /* float offsets into weights_host */
+} qd_policy_op;
+typedef struct qd_policy_desc {
+  int32_t n_ops, n_bufs;
+  int32_t buf_width[4];
+  int32_t obs_dim, act_dim;
+  int32_t logits_buf, logits_off, n_logits;
+  int32_t value_buf, value_off; /* value_buf < 0: no value head */
+} qd_policy_desc;
+size_t qd_policy_packed_bytes(const qd_policy_desc* desc, const qd_policy_op* ops);
+int qd_policy_create(const qd_policy_desc* desc, const qd_policy_op* ops, const float* weights_host, size_t n_weights,
+                     void* packed_device, size_t packed_bytes, qd_policy** out);
+int qd_policy_destroy(qd_policy* policy);
+/* model.forward + value_function + MyBetaDist.deterministic_sample; any of actions / logits / value may be
+ * NULL; prev_actions / prev_truncated may be NULL (= zeros / no episode boundary) */
+int qd_policy_forward(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions,
+                      const uint8_t* prev_truncated, float* actions, float* logits, float* value, void* stream);
+/* T closed-loop steps policy -> vector_step enqueued by one call (2 launches per step, no host round trip):
+ * obs0[N,D] is the observation the first action is computed from, prev_actions0[N,4] (nullable) the action
+ * before it; obs[T,N,D], actions[T,N,4], reward[T,N], truncated[T,N], logits[T,N,n_logits] / value[T,N] nullable.
+ * Same results as T x (qd_policy_forward, qd_step). */
+int qd_rollout_policy(qd_env* env, qd_policy* policy, int T, const float* obs0, const float* prev_actions0, float* obs,
+                      float* actions, float* reward, uint8_t* truncated, float* logits, float* value, void* stream);
+
 /* _get_obs() on the current simulator state, obs[N,D] */
 int qd_observe(qd_env* env, float* obs, void* stream);
 /* get_drone_states() (BaseDroneEnv.py:357-380): states[N, qd_state_dim(model)] */

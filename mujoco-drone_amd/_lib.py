@@ -50,6 +50,21 @@ class QdConfig(C.Structure):
     ]
 
 
+class QdPolicyOp(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("in_buf", C.c_int32), ("in_off", C.c_int32), ("in_dim", C.c_int32),
+                ("out_buf", C.c_int32), ("out_off", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32),
+                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+
+
+class QdPolicyDesc(C.Structure):
+    _fields_ = [("n_ops", C.c_int32), ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * 4), ("obs_dim", C.c_int32),
+                ("act_dim", C.c_int32), ("logits_buf", C.c_int32), ("logits_off", C.c_int32), ("n_logits", C.c_int32),
+                ("value_buf", C.c_int32), ("value_off", C.c_int32)]
+
+
+POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV = 0, 1, 2, 3
+ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+
 # every symbol include/qd.h declares: (restype, argtypes)
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
 _D4 = C.POINTER(C.c_double)
@@ -77,6 +92,12 @@ SIGNATURES = {
     "qd_pid_reset": (_I, [_VP, _VP, _VP]),
     "qd_pid_action": (_I, [_VP, _VP, _VP]),
     "qd_rollout_pid": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP]),
+    "qd_policy_packed_bytes": (C.c_size_t, [C.POINTER(QdPolicyDesc), C.POINTER(QdPolicyOp)]),
+    "qd_policy_create": (_I, [C.POINTER(QdPolicyDesc), C.POINTER(QdPolicyOp), _VP, C.c_size_t, _VP, C.c_size_t,
+                              C.POINTER(_VP)]),
+    "qd_policy_destroy": (_I, [_VP]),
+    "qd_policy_forward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),
     "qd_drone_states": (_I, [_VP, _VP, _VP]),
     "qd_eval_obs": (_I, [_I, _I, _VP, _D4, _VP, _I, _VP]),

@@ -15,6 +15,7 @@
 // Observations are produced row-major [N,D] (what the policy network consumes); a
 // wavefront's 64 rows are one contiguous 64*D*4-byte span, so rows are staged through LDS
 // and written back with full-width coalesced stores.
+#include <vector>
 #include <hip/hip_runtime.h>
 
 #include <cstdarg>
@@ -29,6 +30,7 @@
 #include "qd_model.h"
 #include "qd_obsrew.h"
 #include "qd_pid.h"
+#include "qd_policy.h"
 #include "qd_rng.h"
 
 namespace qd {
@@ -1227,6 +1229,8 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
+
+#include "qd_policy_host.inc"
 
 int qd_observe(qd_env* env, float* obs, void* stream) {
   QD_NEED(env);

@@ -1,0 +1,206 @@
+"""On-device policy inference: the reference's actor / critic networks as layer programs for
+`qd_policy_*` (include/qd.h), compiled from a state dict keyed like the reference's checkpoints
+(`policies/default_policy/policy_state.pkl` -> 'weights', evaluation.py:155-159).
+
+Families (eval mode; constructor arguments as in train_PPO.py:39-45):
+  "RMA_full"        models/PPO/RMA/RMA_model.py:17-110 with train_adaptation=False
+  "RMA_model"       models/PPO/RMA/RMA_model.py:199-292
+  "SimpleMLPmodel"  models/PPO/SimpleMLP/SimpleMLP.py:18-98
+The deterministic action is MyBetaDist's (distributions.py:8-26).  There is no CPU path: everything runs in
+libqd.so's k_policy kernel.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib as L
+
+BN_EPS = 1e-5  # torch.nn.BatchNorm1d default, what the reference's models use
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+class _Program:
+    """accumulates ops and the flat float32 weight blob they index"""
+
+    def __init__(self, weights):
+        self.w = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in weights.items()}
+        self.ops, self.blob, self.n = [], [], 0
+
+    def _put(self, arr):
+        arr = np.ascontiguousarray(arr, dtype=np.float32).ravel()
+        off = self.n
+        self.blob.append(arr)
+        self.n += arr.size
+        return off
+
+    def copy_obs(self, src_off, count, buf, off):
+        self.ops.append(L.QdPolicyOp(L.POL_COPY_OBS, 0, src_off, count, buf, off, count, 0, 0, 0))
+
+    def copy_prev(self, count, buf, off):
+        self.ops.append(L.QdPolicyOp(L.POL_COPY_PREV, 0, 0, count, buf, off, count, 0, 0, 0))
+
+    def fc(self, prefix, src, dst, act):
+        """SlimFC `prefix`: (buf, off) -> (buf, off)"""
+        W, b = self.w[prefix + "._model.0.weight"], self.w[prefix + "._model.0.bias"]
+        out_dim, in_dim = W.shape
+        self.ops.append(L.QdPolicyOp(L.POL_DENSE, src[0], src[1], in_dim, dst[0], dst[1], out_dim,
+                                     {None: L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU}[act], self._put(W), self._put(b)))
+        return out_dim
+
+    def bn(self, prefix, buf, off):
+        """eval-mode BatchNorm1d `prefix` in place"""
+        g, b = self.w[prefix + ".weight"].astype(np.float64), self.w[prefix + ".bias"].astype(np.float64)
+        m, v = self.w[prefix + ".running_mean"].astype(np.float64), self.w[prefix + ".running_var"].astype(np.float64)
+        scale = g / np.sqrt(v + BN_EPS)
+        self.ops.append(L.QdPolicyOp(L.POL_AFFINE, buf, off, len(g), buf, off, len(g), 0, self._put(scale), self._put(b - m * scale)))
+
+
+def _rma_full(p, D, ns, npar, na):
+    X, P, A, B = 0, 1, 2, 3
+    p.copy_obs(0, ns, X, 0); p.copy_prev(na, X, ns); p.copy_obs(D - npar, npar, P, 0)      # RMA_model.py:93-96
+    h = p.fc("param_encoder.0", (P, 0), (A, 0), "tanh")
+    z = p.fc("param_encoder.1", (A, 0), (X, ns + na), None)                                 # :107 z = param_encoder(e)
+    p.fc("_hidden_layers.0", (X, 0), (A, 0), "tanh")                                        # :108 cat(flat_in, z)
+    f = p.fc("_hidden_layers.1", (A, 0), (B, 0), "tanh")
+    p.bn("_hidden_layers.2", B, 0)
+    m = p.fc("_logits.0", (B, 0), (A, 0), "tanh")
+    nl = p.fc("_logits.1", (A, 0), (P, 0), None)
+    m = p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128 if m <= 128 else 256), "tanh")
+    p.fc("_value_branch.2", (A, 128 if m <= 128 else 256), (X, 0), None)
+    return dict(widths=[max(32, ns + na + z), 16, 512 if m > 128 else 256, max(f, 128)], logits=(P, 0, nl), value=(X, 0))
+
+
+def _rma_model(p, D, ns, npar, na):
+    X, P, A, B = 0, 1, 2, 3
+    p.copy_obs(0, ns, X, 0); p.copy_prev(na, X, ns); p.copy_obs(ns, npar, P, 0)            # RMA_model.py:273-285
+    p.fc("param_encoder.0", (P, 0), (A, 0), "tanh")
+    z = p.fc("param_encoder.1", (A, 0), (X, ns + na), "tanh")
+    p.fc("_hidden_layers.0", (X, 0), (A, 0), "tanh")
+    p.fc("_hidden_layers.1", (A, 0), (B, 0), "tanh")
+    p.fc("_hidden_layers.2", (B, 0), (A, 0), "tanh")
+    p.fc("_hidden_layers.3", (A, 0), (B, 0), "tanh")
+    p.bn("_hidden_layers.4", B, 0)
+    p.fc("_logits.0", (B, 0), (A, 0), "tanh")
+    p.fc("_logits.1", (A, 0), (A, 64), "tanh")
+    nl = p.fc("_logits.2", (A, 64), (P, 0), None)
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[max(32, ns + na + z), 16, 256, 128], logits=(P, 0, nl), value=(X, 0))
+
+
+def _simple_mlp(p, D, ns, npar, na):
+    X, P, A, B = 0, 1, 2, 3
+    nl = 0
+    for trunk, buf in (("_logits", X), ("_value_branch", P)):                              # SimpleMLP.py:86-98
+        p.copy_obs(0, D, buf, 0); p.copy_prev(na, buf, D)
+        p.bn(trunk + ".0", buf, 0)
+        p.fc(trunk + ".1", (buf, 0), (A, 0), "tanh")
+        p.fc(trunk + ".2", (A, 0), (B, 0), "tanh")
+        p.fc(trunk + ".3", (B, 0), (A, 0), "tanh")
+        p.fc(trunk + ".4", (A, 0), (B, 0), "tanh")
+        p.bn(trunk + ".5", B, 0)
+        p.fc(trunk + ".6", (B, 0), (A, 0), "tanh")
+        p.fc(trunk + ".7", (A, 0), (A, 128), "tanh")
+        n = p.fc(trunk + ".8", (A, 128), (buf, 0), None)
+        nl = n if trunk == "_logits" else nl
+    return dict(widths=[32, 32, 256, 128], logits=(X, 0, nl), value=(P, 0))
+
+
+_FAMILIES = {"RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp}
+
+
+def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):
+    """state dict -> (qd_policy_desc, qd_policy_op array, float32 weight blob); host only"""
+    if family not in _FAMILIES:
+        raise ValueError("unknown policy family %r (have %s)" % (family, sorted(_FAMILIES)))
+    prog = _Program(weights)
+    lay = _FAMILIES[family](prog, int(obs_dim), int(num_states), int(num_params), int(num_actions))
+    d = L.QdPolicyDesc()
+    d.n_ops, d.n_bufs = len(prog.ops), 4
+    d.buf_width[:] = [int(x) for x in lay["widths"]]
+    d.obs_dim, d.act_dim = int(obs_dim), int(num_actions)
+    d.logits_buf, d.logits_off, d.n_logits = lay["logits"]
+    d.value_buf, d.value_off = lay["value"]
+    ops = (L.QdPolicyOp * len(prog.ops))(*prog.ops)
+    return d, ops, np.concatenate(prog.blob).astype(np.float32)
+
+
+class DevicePolicy:
+    """One of the reference's policy networks, resident on the GPU.
+
+    policy = DevicePolicy("RMA_full", state_dict)            # keys as in the reference's checkpoints
+    actions = policy.forward(obs, prev_actions)               # [N,4] CUDA tensor; deterministic (Beta mean) action
+    """
+
+    def __init__(self, family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4, device="cuda:0"):
+        self.lib = L.lib()
+        self.device = torch.device(device)
+        self.family, self.obs_dim, self.act_dim = family, int(obs_dim), int(num_actions)
+        d, ops, blob = compile_program(family, weights, obs_dim, num_states, num_params, num_actions)
+        self.n_logits = int(d.n_logits)
+        nbytes = self.lib.qd_policy_packed_bytes(C.byref(d), ops)
+        if nbytes == 0:
+            raise ValueError("invalid policy program: " + L.last_error())
+        with torch.cuda.device(self.device):
+            self.packed = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            handle = C.c_void_p()
+            L.check(self.lib.qd_policy_create(C.byref(d), ops, blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(self.packed),
+                                              nbytes, C.byref(handle)))
+        self.handle = handle
+        self.n_weights, self.n_ops = int(blob.size), int(d.n_ops)
+
+    def __del__(self):
+        h = getattr(self, "handle", None)
+        if h:
+            self.lib.qd_policy_destroy(h)
+            self.handle = None
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, t, shape):
+        t = torch.as_tensor(t, device=self.device)
+        t = t.to(dtype=torch.float32).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
+        return t
+
+    def forward(self, obs, prev_actions=None, prev_truncated=None, want_logits=False, want_value=False, out=None):
+        """model.forward + MyBetaDist.deterministic_sample [+ value_function] for obs [N,D]: actions [N,4]
+        (, logits [N,8], value [N])"""
+        n = int(obs.shape[0])
+        obs = self._f32(obs, (n, self.obs_dim))
+        prev = self._f32(prev_actions, (n, self.act_dim)) if prev_actions is not None else None
+        tr = prev_truncated.to(device=self.device, dtype=torch.uint8).contiguous() if prev_truncated is not None else None
+        kw = dict(dtype=torch.float32, device=self.device)
+        actions = torch.empty((n, self.act_dim), **kw) if out is None else out
+        logits = torch.empty((n, self.n_logits), **kw) if want_logits else None
+        value = torch.empty((n,), **kw) if want_value else None
+        L.check(self.lib.qd_policy_forward(self.handle, n, _ptr(obs), _ptr(prev), _ptr(tr), _ptr(actions), _ptr(logits),
+                                           _ptr(value), self._stream()))
+        res = (actions,) + ((logits,) if want_logits else ()) + ((value,) if want_value else ())
+        return res[0] if len(res) == 1 else res
+
+    def rollout(self, env, T, obs0, prev_actions0=None, want_logits=False, want_value=False):
+        """T closed-loop steps policy -> vector_step on a DeviceEnv, enqueued by one call:
+        dict(obs [T,N,D], actions [T,N,4], reward [T,N], truncated [T,N][, logits, value])"""
+        T, n = int(T), env.n
+        kw = dict(dtype=torch.float32, device=self.device)
+        obs0 = self._f32(obs0, (n, env.D))
+        prev = self._f32(prev_actions0, (n, 4)) if prev_actions0 is not None else None
+        out = dict(obs=torch.empty((T, n, env.D), **kw), actions=torch.empty((T, n, 4), **kw),
+                   reward=torch.empty((T, n), **kw), truncated=torch.empty((T, n), dtype=torch.uint8, device=self.device))
+        if want_logits:
+            out["logits"] = torch.empty((T, n, self.n_logits), **kw)
+        if want_value:
+            out["value"] = torch.empty((T, n), **kw)
+        L.check(self.lib.qd_rollout_policy(env.handle, self.handle, T, _ptr(obs0), _ptr(prev), _ptr(out["obs"]),
+                                           _ptr(out["actions"]), _ptr(out["reward"]), _ptr(out["truncated"]),
+                                           _ptr(out.get("logits")), _ptr(out.get("value")), self._stream()))
+        return out

@@ -1,0 +1,93 @@
+"""GPU parity of the on-device policy inference (qd_policy_*) against the outputs of the reference's own
+model classes (tests/golden/policy_vectors.npz) and against the float64 policy oracle on larger batches.
+Tolerance: the reference computes in float32; the device's f32 MFMA chain and a fast tanh differ from it by a few
+1e-6 on O(1) logits -> 2e-5 absolute."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+HERE = os.path.dirname(os.path.abspath(__file__))
+TAGS = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "SimpleMLPmodel"}
+
+
+@pytest.fixture(scope="module")
+def PG():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    return np.load(os.path.join(HERE, "golden", "policy_vectors.npz"))
+
+
+def weights_of(PG, tag):
+    return {k: PG[tag + "/" + k] for k in PG[tag + "_keys"]}
+
+
+@pytest.mark.parametrize("tag", list(TAGS))
+def test_policy_forward_vs_reference_models(PG, tag):
+    from mujoco_drone_amd.policy import DevicePolicy
+    pol = DevicePolicy(TAGS[tag], weights_of(PG, tag))
+    obs, prev = torch.tensor(PG["obs"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda")
+    act, logits, value = pol.forward(obs, prev, want_logits=True, want_value=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), PG[tag + "_logits"], atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), PG[tag + "_value"], atol=2e-5)
+    np.testing.assert_allclose(act.cpu().numpy(), PG[tag + "_action"], atol=1e-5)
+    # actions only (the rollout configuration) gives the same actions
+    np.testing.assert_array_equal(pol.forward(obs, prev).cpu().numpy(), act.cpu().numpy())
+
+
+@pytest.mark.parametrize("n", [1, 17, 4096 + 5])
+def test_policy_forward_vs_oracle_ragged_batches(PG, n):
+    """batch sizes that are not multiples of the 16-env tile; previous actions absent / zeroed at episode starts"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    rng = np.random.default_rng(n)
+    w = weights_of(PG, "rma_full")
+    pol = DevicePolicy("RMA_full", w)
+    obs = rng.normal(scale=1.5, size=(n, 22)).astype(np.float32)
+    obs[:, 16:] = (np.array([1, 0.17, 7, 0.01, 1.2, 0.3]) * (1 + 0.1 * rng.normal(size=(n, 6)))).astype(np.float32)
+    prev = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+    tr = (rng.uniform(size=n) < 0.3).astype(np.uint8)
+    act, logits, value = pol.forward(torch.tensor(obs, device="cuda"), torch.tensor(prev, device="cuda"),
+                                     torch.tensor(tr, device="cuda"), want_logits=True, want_value=True)
+    wl, wv = P.rma_full(w, obs, prev * (1 - tr[:, None]))
+    np.testing.assert_allclose(logits.cpu().numpy(), wl, atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), wv, atol=2e-5)
+    np.testing.assert_allclose(act.cpu().numpy(), P.beta_mean_action(wl), atol=1e-5)
+    a0 = pol.forward(torch.tensor(obs, device="cuda"))              # no previous action at all = zeros
+    wl0, _ = P.rma_full(w, obs, np.zeros((n, 4)))
+    np.testing.assert_allclose(a0.cpu().numpy(), P.beta_mean_action(wl0), atol=1e-5)
+
+
+def test_policy_closed_loop_rollout(PG):
+    """qd_rollout_policy == T x (qd_policy_forward, qd_step): observations feed the policy, its actions feed the env and
+    come back as prev_actions, zeroed where the env was just re-sampled; and against the float64 oracle policy fed
+    with the device's observations"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    from oracle import policy_ref as P
+    w = weights_of(PG, "rma_full")
+    pol = DevicePolicy("RMA_full", w)
+    cfg = dict(base_config, num_drones=200, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=9, auto_reset=True)
+    T = 30
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    assert torch.equal(o1, o2)
+    out = pol.rollout(e1._dev, T, o1, want_logits=True)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a = pol.forward(obs, prev, tr)
+        np.testing.assert_allclose(out["actions"][t].cpu().numpy(), a.cpu().numpy(), atol=1e-6)
+        wl, _ = P.rma_full(w, obs.cpu().numpy(), np.zeros((200, 4)) if prev is None else prev.cpu().numpy() * (1 - tr.cpu().numpy()[:, None]))
+        np.testing.assert_allclose(out["logits"][t].cpu().numpy(), wl, atol=3e-5)
+        ob, rw, trn = e2.vector_step_tensor(a)
+        obs, prev, tr = ob.clone(), a, trn.clone()
+        np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), atol=1e-5)
+        assert torch.equal(out["truncated"][t], tr)
+    assert int(out["truncated"].sum()) == 3 * 200      # max_steps = 9: every env truncated three times in 30 steps
+    with pytest.raises(ValueError):
+        pol.rollout(e1._dev, 2, torch.zeros((200, 21), device="cuda"))

@@ -26,3 +26,31 @@ def test_policy_oracle_vs_reference_models(PG, tag):
     np.testing.assert_allclose(value, PG[tag + "_value"], atol=3e-6)
     np.testing.assert_allclose(P.beta_mean_action(PG[tag + "_logits"]), PG[tag + "_action"], atol=1e-6)
     np.testing.assert_allclose(P.beta_logp(PG[tag + "_logits"], PG[tag + "_action"]), PG[tag + "_logp"], atol=2e-5)
+
+
+FAMILY_OF = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "SimpleMLPmodel"}
+
+
+@pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp"])
+def test_policy_programs_compile_on_the_host(PG, tag):
+    """state dict -> layer program -> qd_policy_packed_bytes (host-only entry point of the C ABI): the program passes
+    the library's validation and the packed blob has the size the padded 16x16 tiling implies"""
+    import ctypes as C
+    from mujoco_drone_amd import _lib as L
+    from mujoco_drone_amd.policy import compile_program
+    d, ops, blob = compile_program(FAMILY_OF[tag], weights_of(PG, tag))
+    nbytes = L.lib().qd_policy_packed_bytes(C.byref(d), ops)
+    assert nbytes > 0, L.last_error()
+    want = 0
+    for op in ops:
+        if op.kind == L.POL_DENSE:
+            k16, nt = (op.in_dim + 15) // 16, (op.out_dim + 15) // 16
+            want += nt * k16 * 256 + nt * 16
+        elif op.kind == L.POL_AFFINE:
+            want += (2 * op.out_dim + 3) // 4 * 4
+    assert nbytes == 4 * want
+    assert d.n_logits == 8 and blob.dtype == np.float32
+    # a program that reads outside its buffer is refused with a message, not run
+    bad = type(ops)(*ops)
+    bad[3].in_dim = 5000
+    assert L.lib().qd_policy_packed_bytes(C.byref(d), bad) == 0 and "op 3" in L.last_error()
