@@ -207,9 +207,11 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
  * The caller owns the device buffer the packed weights live in (qd_policy_packed_bytes). */
 enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3 };
 enum { QD_ACT_NONE = 0, QD_ACT_TANH = 1, QD_ACT_RELU = 2 };
+enum { QD_POL_VALUE_ONLY = 1 };
 typedef struct qd_policy qd_policy;
 typedef struct qd_policy_op {
   int32_t kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act;
+  int32_t flags, reserved0;     /* QD_POL_VALUE_ONLY: the op feeds only the value head, skipped when value == NULL */
   int64_t w_off, b_off;         /* float offsets into weights_host */
 } qd_policy_op;
 typedef struct qd_policy_desc {

@@ -53,7 +53,7 @@ class QdConfig(C.Structure):
 class QdPolicyOp(C.Structure):
     _fields_ = [("kind", C.c_int32), ("in_buf", C.c_int32), ("in_off", C.c_int32), ("in_dim", C.c_int32),
                 ("out_buf", C.c_int32), ("out_off", C.c_int32), ("out_dim", C.c_int32), ("act", C.c_int32),
-                ("w_off", C.c_int64), ("b_off", C.c_int64)]
+                ("flags", C.c_int32), ("reserved0", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
 class QdPolicyDesc(C.Structure):
@@ -64,6 +64,7 @@ class QdPolicyDesc(C.Structure):
 
 POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV = 0, 1, 2, 3
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
+POL_VALUE_ONLY = 1
 
 # every symbol include/qd.h declares: (restype, argtypes)
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64

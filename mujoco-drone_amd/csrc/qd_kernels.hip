@@ -897,6 +897,9 @@ int qd_version(void) { return QD_VERSION; }
 int qd_debug_read_stamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -4;
 }
+int qd_debug_read_pstamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd::qd_pstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
+}
 int qd_debug_read_rstamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_rstamps), sizeof(unsigned long long) * 64 * 2) == hipSuccess ? 0 : -4;
 }

@@ -12,38 +12,60 @@
 // How it maps to CDNA4: this is the one GEMM-shaped piece of the path, so it runs on the matrix cores in exact f32
 // (v_mfma_f32_16x16x4_f32: bit-for-bit an fmaf chain, the reference computes in float32).  One 256-thread workgroup
 // owns a tile of 16 envs (M = 16); activations never leave LDS; for each layer the four waves split the output
-// features into 16-wide tiles, up to four tiles per wave at a time sharing one A operand read.  Weights are pre-packed
-// on the host into the order the lanes consume them (one coalesced 1 KiB load per wave per 16x16 k-block) and streamed
-// from L2 through a register ring several k-blocks ahead of the MFMAs, because at 16 envs per workgroup the kernel is
-// an L2-latency chain, not a FLOP problem (57.8k MAC per env for RMA_full's actor).
+// features into 16-wide tiles, up to four tiles per wave at a time sharing one A operand read.  At 16 envs per
+// workgroup the kernel is a latency chain, not a FLOP problem (57.8k MAC per env for RMA_full's actor), so:
+//   - weights are pre-packed on the host in the order the lanes consume them (one coalesced 1 KiB load per wave per
+//     16x16 k-block) and each wave streams them from L2 one step ahead of its MFMAs, across layer boundaries;
+//   - the program is pre-digested on the host into per-wave step descriptors that the kernel mirrors in LDS together
+//     with the biases, so that interpreting it costs LDS reads, not chains of dependent scalar loads.
 #pragma once
 
 #include "qd_math.h"
 
 namespace qd {
 
-constexpr int POL_MAX_OPS = 24, POL_MAX_BUFS = 4, POL_TILE = 16, POL_THREADS = 256, POL_RING = 4;
+constexpr int POL_MAX_OPS = 24, POL_MAX_BUFS = 4, POL_TILE = 16, POL_THREADS = 256, POL_WAVES = POL_THREADS / 64;
+constexpr int POL_KC = 4;       // k-blocks (of 16 inputs) per step
+constexpr int POL_DESC = 16;    // ints per op descriptor
+constexpr int POL_SDESC = 32;   // ints per step descriptor
 enum { POL_DENSE = 0, POL_AFFINE = 1, POL_COPY_OBS = 2, POL_COPY_PREV = 3 };
 enum { POL_ACT_NONE = 0, POL_ACT_TANH = 1, POL_ACT_RELU = 2 };
+enum { POL_FLAG_VALUE_ONLY = 1 };  // the op only feeds the value head: skipped when no value output is requested
+enum { POL_STEP_FIRST = 1, POL_STEP_LAST = 2, POL_STEP_VALUE_ONLY = 4 };
 
-struct PolOp {
-  int kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act;
-  int k16, ntiles;          // DENSE: k-blocks of 16 inputs, 16-wide output tiles (both padded, the padding holds zeros)
-  long long w_off, b_off;   // float offsets into the packed device blob (AFFINE: scale / shift)
-};
+// op descriptor (POL_DESC ints, written by pol_compile)
+enum { OD_KIND = 0, OD_FLAGS, OD_SRC_OFF, OD_COUNT, OD_OUT, OD_LD_OUT, OD_SCALE, OD_SHIFT };
+// step descriptor (POL_SDESC ints): one wave, POL_KC k-blocks of up to four output tiles of one dense op.
+// SD_LANE + u: 1 if tile slot u is used (lanes read consecutive float4s) else 0 (all lanes read one word);
+// SD_OFF + 4 u + d: float4 offset of k-block d of tile slot u in the weight region (0 for unused slots, the last live
+// block repeated past klive): the kernel's loads are pure address arithmetic on these, no conditions
+enum { SD_OP = 0, SD_U, SD_FLAGS, SD_KLIVE, SD_A, SD_LD_IN, SD_BIAS, SD_OUT, SD_LD_OUT, SD_COLS, SD_ACT, SD_LANE = 12, SD_OFF = 16 };
 
 struct PolArgs {
-  PolOp ops[POL_MAX_OPS];
-  int n_ops, n_bufs;
-  int ld[POL_MAX_BUFS], base[POL_MAX_BUFS];  // row stride / first float of each activation buffer in LDS
-  int lds_floats;
+  const float* packed;        // [program ints | small floats | packed weights]
+  int prog_ints;              // op descriptors, then the four waves' step lists
+  int small_floats;           // biases, affine scale / shift
+  int n_ops;
+  int step_base[POL_WAVES];   // int offset of each wave's step list in the program
+  int act_floats;             // activation buffers (LDS), zero-initialised
   int obs_dim, act_dim;
-  int logits_buf, logits_off, n_logits;
-  int value_buf, value_off;                  // value_buf < 0: the program has no value head
-  const float* packed;
+  int logits_lds, ld_logits, n_logits;   // LDS float offset of env row 0's logits, row stride
+  int value_lds, ld_value;               // value_lds < 0: the program has no value head
+  long long weights_off;      // float offset of the packed weights in the blob
 };
 
 typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
+
+#ifdef QD_STAMPS
+// diagnostic build only: s_memrealtime (100 MHz) stamps of wave 0 of workgroup 0 after every op's barrier
+__device__ unsigned long long qd_pstamps[64];
+#define POL_STAMP(k)                                                                                                  \
+  do {                                                                                                                \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && (k) < 64) qd_pstamps[(k)] = __builtin_amdgcn_s_memrealtime();              \
+  } while (0)
+#else
+#define POL_STAMP(k)
+#endif
 
 __device__ __forceinline__ float pol_act(float x, int act) {
   if (act == POL_ACT_TANH) {
@@ -55,60 +77,73 @@ __device__ __forceinline__ float pol_act(float x, int act) {
   return x;
 }
 
-// U output tiles (tile, tile + 4, ...) of one dense layer for this wave; A operand shared by the U tiles
-template <int U>
-__device__ __forceinline__ void pol_dense_tiles(const PolArgs& p, const PolOp& op, float* lds, int tile0, int lane) {
-  const int i = lane & 15, g = lane >> 4;
-  const float* a_ptr = lds + p.base[op.in_buf] + i * p.ld[op.in_buf] + op.in_off + g * 4;
-  const float4* w_ptr[U];
-  pol_f32x4 acc[U];
+struct PolStep {
+  int op, U, flags, klive, a, ld_in, bias, out, ld_out, cols, act;
+  int lane_mul[4];
+  int off[4][POL_KC];
+};
+__device__ __forceinline__ int pol_sgpr(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ PolStep pol_read_step(const int* prog, int idx) {
+  const int4* q = reinterpret_cast<const int4*>(prog + idx);
+  const int4 a = q[0], b = q[1], c = q[2], d = q[3];
+  PolStep s;
+  // the descriptor is the same for all lanes: keep it in scalar registers
+  s.op = pol_sgpr(a.x); s.U = pol_sgpr(a.y); s.flags = pol_sgpr(a.z); s.klive = pol_sgpr(a.w);
+  s.a = pol_sgpr(b.x); s.ld_in = pol_sgpr(b.y); s.bias = pol_sgpr(b.z); s.out = pol_sgpr(b.w);
+  s.ld_out = pol_sgpr(c.x); s.cols = pol_sgpr(c.y); s.act = pol_sgpr(c.z);
+  s.lane_mul[0] = pol_sgpr(d.x); s.lane_mul[1] = pol_sgpr(d.y); s.lane_mul[2] = pol_sgpr(d.z); s.lane_mul[3] = pol_sgpr(d.w);
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int tile = tile0 + 4 * u;
-    w_ptr[u] = reinterpret_cast<const float4*>(p.packed + op.w_off) + ((size_t)tile * op.k16) * 64 + lane;
-    const float b = p.packed[op.b_off + tile * 16 + i];
-    acc[u] = pol_f32x4{b, b, b, b};
+  for (int u = 0; u < 4; u++) {
+    const int4 o = q[4 + u];
+    s.off[u][0] = pol_sgpr(o.x); s.off[u][1] = pol_sgpr(o.y); s.off[u][2] = pol_sgpr(o.z); s.off[u][3] = pol_sgpr(o.w);
   }
-  // register ring: the weights of k-block kb + POL_RING are in flight while k-block kb is multiplied
-  float4 ring[POL_RING][U];
-  const int k16 = op.k16;
-#pragma unroll
-  for (int d = 0; d < POL_RING; d++) {
-    const int kb = min(d, k16 - 1);  // clamped: short layers re-read their last block instead of branching
-#pragma unroll
-    for (int u = 0; u < U; u++) ring[d][u] = w_ptr[u][(size_t)kb * 64];
+  return s;
+}
+// next step of this wave's list that runs (value-only steps are skipped when no value is wanted); lists end with a
+// sentinel step (op = n_ops, U = 0) that is returned forever
+__device__ __forceinline__ PolStep pol_fetch(const int* prog, int& idx, bool want_value, int n_ops) {
+  PolStep s = pol_read_step(prog, idx);
+  while (s.op < n_ops && !want_value && (s.flags & POL_STEP_VALUE_ONLY)) {
+    idx += POL_SDESC;
+    s = pol_read_step(prog, idx);
   }
-  for (int kb0 = 0; kb0 < k16; kb0 += POL_RING) {
+  if (s.op < n_ops) idx += POL_SDESC;
+  return s;
+}
+
+typedef float4 PolBuf[POL_KC][4];
+
+// the POL_KC * 4 weight loads of one step: always that many instructions and no conditions (the descriptor carries
+// every offset), so the compiler can count them and wait for exactly the loads it needs
+__device__ __forceinline__ void pol_issue(const float4* weights, const PolStep& s, PolBuf& buf, int lane) {
 #pragma unroll
-    for (int d = 0; d < POL_RING; d++) {
-      const int kb = kb0 + d;
-      if (kb < k16) {  // wave-uniform
-        const float4 a4 = *reinterpret_cast<const float4*>(a_ptr + kb * 16);
-        float4 w[U];
+  for (int u = 0; u < 4; u++) {
+    const float4* src = weights + lane * s.lane_mul[u];
 #pragma unroll
-        for (int u = 0; u < U; u++) w[u] = ring[d][u];
-        const int kn = min(kb + POL_RING, k16 - 1);
-#pragma unroll
-        for (int u = 0; u < U; u++) ring[d][u] = w_ptr[u][(size_t)kn * 64];
-#pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.x, w[u].x, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.y, w[u].y, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.z, w[u].z, acc[u], 0, 0, 0);
-#pragma unroll
-        for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a4.w, w[u].w, acc[u], 0, 0, 0);
-      }
+    for (int d = 0; d < POL_KC; d++) {
+#ifdef POL_EXP_NOLOAD
+      buf[d][u] = make_float4(0.f, 0.f, 0.f, (float)s.off[u][d] + (float)(size_t)src);  // experiment: no weight traffic
+#else
+      buf[d][u] = src[s.off[u][d]];
+#endif
     }
   }
-  // D layout: lane holds rows 4g..4g+3 of column i of each tile
-  float* o_ptr = lds + p.base[op.out_buf] + (4 * g) * p.ld[op.out_buf] + op.out_off;
+}
+
+template <int U>
+__device__ __forceinline__ void pol_mac(const PolStep& s, const PolBuf& w, const float* a_ptr, pol_f32x4 (&acc)[4]) {
 #pragma unroll
-  for (int u = 0; u < U; u++) {
-    const int col = (tile0 + 4 * u) * 16 + i;
-    if (col < op.out_dim) {
+  for (int d = 0; d < POL_KC; d++) {
+    if (d < s.klive) {  // wave-uniform; no global memory operation inside
+      const float4 a = *reinterpret_cast<const float4*>(a_ptr + d * 16);
 #pragma unroll
-      for (int v = 0; v < 4; v++) o_ptr[v * p.ld[op.out_buf] + col] = pol_act(acc[u][v], op.act);
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[d][u].x, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[d][u].y, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[d][u].z, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < U; u++) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[d][u].w, acc[u], 0, 0, 0);
     }
   }
 }
@@ -119,64 +154,112 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
                                                         float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
   const int env0 = blockIdx.x * POL_TILE;
-  for (int k = tid; k < p.lds_floats; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
+  const bool want_value = value != nullptr;
+  POL_STAMP(0);
+  // LDS: [activations | program | small]
+  int* prog = reinterpret_cast<int*>(lds + p.act_floats);
+  float* small = lds + p.act_floats + p.prog_ints;
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.packed);
+    float4* dst = reinterpret_cast<float4*>(lds + p.act_floats);
+    const int n4 = (p.prog_ints + p.small_floats) >> 2;
+    for (int k = tid; k < n4; k += POL_THREADS) dst[k] = src[k];
+    for (int k = tid; k < p.act_floats; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
+  }
   __syncthreads();
+  POL_STAMP(1);
+  const float4* weights = reinterpret_cast<const float4*>(p.packed + p.weights_off);
+  // the weight stream starts before the inputs are gathered
+  int sidx = p.step_base[wave];
+  PolBuf wnext, wcur;
+  PolStep cur = pol_fetch(prog, sidx, want_value, p.n_ops);
+  pol_issue(weights, cur, wnext, lane);
+  pol_f32x4 acc[4];
   for (int o = 0; o < p.n_ops; o++) {
-    const PolOp& op = p.ops[o];
-    if (op.kind == POL_DENSE) {
-      // this wave's tiles: wave, wave + 4, ...; up to four at a time
-      for (int t = wave; t < op.ntiles; t += 16) {
-        const int left = (op.ntiles - t + 3) >> 2;
-        if (left >= 4) pol_dense_tiles<4>(p, op, lds, t, lane);
-        else if (left == 3) { pol_dense_tiles<2>(p, op, lds, t, lane); pol_dense_tiles<1>(p, op, lds, t + 8, lane); }
-        else if (left == 2) pol_dense_tiles<2>(p, op, lds, t, lane);
-        else pol_dense_tiles<1>(p, op, lds, t, lane);
+    const int* od = prog + o * POL_DESC;
+    const int kind = od[OD_KIND];
+    if (!want_value && (od[OD_FLAGS] & POL_FLAG_VALUE_ONLY)) continue;  // uniform over the workgroup
+    if (kind == POL_DENSE) {
+      while (cur.op == o) {
+        const PolStep nx = pol_fetch(prog, sidx, want_value, p.n_ops);
+#pragma unroll
+        for (int d = 0; d < POL_KC; d++)
+#pragma unroll
+          for (int u = 0; u < 4; u++) wcur[d][u] = wnext[d][u];  // this step's weights, requested one step ago
+        pol_issue(weights, nx, wnext, lane);
+        if (cur.flags & POL_STEP_FIRST) {
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const float b = u < cur.U ? small[cur.bias + u * (POL_WAVES * 16) + li] : 0.f;
+            acc[u] = pol_f32x4{b, b, b, b};
+          }
+        }
+        const float* a_ptr = lds + cur.a + li * cur.ld_in + lg * 4;
+        if (cur.U == 4) pol_mac<4>(cur, wcur, a_ptr, acc);
+        else if (cur.U == 2) pol_mac<2>(cur, wcur, a_ptr, acc);
+        else pol_mac<1>(cur, wcur, a_ptr, acc);
+        if (cur.flags & POL_STEP_LAST) {
+          // D layout: lane holds rows 4 lg .. 4 lg + 3 of column li of each tile
+          float* o_ptr = lds + cur.out + (4 * lg) * cur.ld_out + li;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            if (u < cur.U && u * (POL_WAVES * 16) + li < cur.cols) {
+#pragma unroll
+              for (int v = 0; v < 4; v++) o_ptr[v * cur.ld_out + u * (POL_WAVES * 16)] = pol_act(acc[u][v], cur.act);
+            }
+          }
+        }
+        cur = nx;
       }
-    } else if (op.kind == POL_AFFINE) {
-      float* b = lds + p.base[op.out_buf] + op.out_off;
-      const int ld = p.ld[op.out_buf];
-      for (int k = tid; k < POL_TILE * op.out_dim; k += POL_THREADS) {
-        const int r = k / op.out_dim, c = k - r * op.out_dim;
-        b[r * ld + c] = fmaf(b[r * ld + c], p.packed[op.w_off + c], p.packed[op.b_off + c]);
+    } else if (kind == POL_AFFINE) {
+      float* b = lds + od[OD_OUT];
+      const int ld = od[OD_LD_OUT], n = od[OD_COUNT];
+      const float* sc = small + od[OD_SCALE];
+      const float* sh = small + od[OD_SHIFT];
+      for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
+        const int r = k / n, c = k - r * n;
+        b[r * ld + c] = fmaf(b[r * ld + c], sc[c], sh[c]);
       }
     } else {
-      float* b = lds + p.base[op.out_buf] + op.out_off;
-      const int ld = p.ld[op.out_buf];
-      for (int k = tid; k < POL_TILE * op.in_dim; k += POL_THREADS) {
-        const int r = k / op.in_dim, c = k - r * op.in_dim;
+      float* b = lds + od[OD_OUT];
+      const int ld = od[OD_LD_OUT], n = od[OD_COUNT], so = od[OD_SRC_OFF];
+      for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
+        const int r = k / n, c = k - r * n;
         const int e = env0 + r;
         float v = 0.f;
         if (e < n_envs) {
-          if (op.kind == POL_COPY_OBS) v = obs[(size_t)e * p.obs_dim + op.in_off + c];
-          else if (prev_actions && !(prev_truncated && prev_truncated[e])) v = prev_actions[(size_t)e * p.act_dim + op.in_off + c];
+          if (kind == POL_COPY_OBS) v = obs[(size_t)e * p.obs_dim + so + c];
+          else if (prev_actions && !(prev_truncated && prev_truncated[e])) v = prev_actions[(size_t)e * p.act_dim + so + c];
         }
         b[r * ld + c] = v;
       }
     }
     __syncthreads();
+    POL_STAMP(2 + o);
   }
   // outputs: logits, MyBetaDist.deterministic_sample (distributions.py:8-26), value
-  const float* lg = lds + p.base[p.logits_buf] + p.logits_off;
-  const int ldl = p.ld[p.logits_buf];
+  const float* lgt = lds + p.logits_lds;
+  const int ldl = p.ld_logits;
   if (logits)
     for (int k = tid; k < POL_TILE * p.n_logits; k += POL_THREADS) {
       const int r = k / p.n_logits, c = k - r * p.n_logits;
-      if (env0 + r < n_envs) logits[(size_t)(env0 + r) * p.n_logits + c] = lg[r * ldl + c];
+      if (env0 + r < n_envs) logits[(size_t)(env0 + r) * p.n_logits + c] = lgt[r * ldl + c];
     }
   if (actions) {
     const int h = p.n_logits >> 1;
     for (int k = tid; k < POL_TILE * h; k += POL_THREADS) {
       const int r = k / h, c = k - r * h;
       if (env0 + r < n_envs) {
-        const float la = qclamp(lg[r * ldl + c], -50.f, 50.f), lb = qclamp(lg[r * ldl + h + c], -50.f, 50.f);
+        const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + h + c], -50.f, 50.f);
         const float al = log1pf(__expf(la)) + 1.0f, be = log1pf(__expf(lb)) + 1.0f;
         actions[(size_t)(env0 + r) * p.act_dim + c] = al * __builtin_amdgcn_rcpf(al + be);
       }
     }
   }
-  if (value && p.value_buf >= 0 && tid < POL_TILE && env0 + tid < n_envs)
-    value[env0 + tid] = lds[p.base[p.value_buf] + tid * p.ld[p.value_buf] + p.value_off];
+  if (want_value && p.value_lds >= 0 && tid < POL_TILE && env0 + tid < n_envs) value[env0 + tid] = lds[p.value_lds + tid * p.ld_value];
+  POL_STAMP(2 + p.n_ops);
 }
 
 }  // namespace qd

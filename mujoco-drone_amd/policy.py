@@ -29,6 +29,7 @@ class _Program:
     def __init__(self, weights):
         self.w = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in weights.items()}
         self.ops, self.blob, self.n = [], [], 0
+        self.flags = 0   # set to POL_VALUE_ONLY while the value head's ops are emitted
 
     def _put(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32).ravel()
@@ -38,17 +39,18 @@ class _Program:
         return off
 
     def copy_obs(self, src_off, count, buf, off):
-        self.ops.append(L.QdPolicyOp(L.POL_COPY_OBS, 0, src_off, count, buf, off, count, 0, 0, 0))
+        self.ops.append(L.QdPolicyOp(L.POL_COPY_OBS, 0, src_off, count, buf, off, count, 0, self.flags, 0, 0, 0))
 
     def copy_prev(self, count, buf, off):
-        self.ops.append(L.QdPolicyOp(L.POL_COPY_PREV, 0, 0, count, buf, off, count, 0, 0, 0))
+        self.ops.append(L.QdPolicyOp(L.POL_COPY_PREV, 0, 0, count, buf, off, count, 0, self.flags, 0, 0, 0))
 
     def fc(self, prefix, src, dst, act):
         """SlimFC `prefix`: (buf, off) -> (buf, off)"""
         W, b = self.w[prefix + "._model.0.weight"], self.w[prefix + "._model.0.bias"]
         out_dim, in_dim = W.shape
         self.ops.append(L.QdPolicyOp(L.POL_DENSE, src[0], src[1], in_dim, dst[0], dst[1], out_dim,
-                                     {None: L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU}[act], self._put(W), self._put(b)))
+                                     {None: L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU}[act], self.flags, 0,
+                                     self._put(W), self._put(b)))
         return out_dim
 
     def bn(self, prefix, buf, off):
@@ -56,7 +58,8 @@ class _Program:
         g, b = self.w[prefix + ".weight"].astype(np.float64), self.w[prefix + ".bias"].astype(np.float64)
         m, v = self.w[prefix + ".running_mean"].astype(np.float64), self.w[prefix + ".running_var"].astype(np.float64)
         scale = g / np.sqrt(v + BN_EPS)
-        self.ops.append(L.QdPolicyOp(L.POL_AFFINE, buf, off, len(g), buf, off, len(g), 0, self._put(scale), self._put(b - m * scale)))
+        self.ops.append(L.QdPolicyOp(L.POL_AFFINE, buf, off, len(g), buf, off, len(g), 0, self.flags, 0, self._put(scale),
+                                     self._put(b - m * scale)))
 
 
 def _rma_full(p, D, ns, npar, na):
@@ -69,6 +72,7 @@ def _rma_full(p, D, ns, npar, na):
     p.bn("_hidden_layers.2", B, 0)
     m = p.fc("_logits.0", (B, 0), (A, 0), "tanh")
     nl = p.fc("_logits.1", (A, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
     m = p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
     p.fc("_value_branch.1", (A, 0), (A, 128 if m <= 128 else 256), "tanh")
     p.fc("_value_branch.2", (A, 128 if m <= 128 else 256), (X, 0), None)
@@ -88,6 +92,7 @@ def _rma_model(p, D, ns, npar, na):
     p.fc("_logits.0", (B, 0), (A, 0), "tanh")
     p.fc("_logits.1", (A, 0), (A, 64), "tanh")
     nl = p.fc("_logits.2", (A, 64), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
     p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
     p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
     p.fc("_value_branch.2", (A, 128), (X, 0), None)
@@ -98,6 +103,7 @@ def _simple_mlp(p, D, ns, npar, na):
     X, P, A, B = 0, 1, 2, 3
     nl = 0
     for trunk, buf in (("_logits", X), ("_value_branch", P)):                              # SimpleMLP.py:86-98
+        p.flags = 0 if trunk == "_logits" else L.POL_VALUE_ONLY
         p.copy_obs(0, D, buf, 0); p.copy_prev(na, buf, D)
         p.bn(trunk + ".0", buf, 0)
         p.fc(trunk + ".1", (buf, 0), (A, 0), "tanh")

@@ -41,14 +41,23 @@ def test_policy_programs_compile_on_the_host(PG, tag):
     d, ops, blob = compile_program(FAMILY_OF[tag], weights_of(PG, tag))
     nbytes = L.lib().qd_policy_packed_bytes(C.byref(d), ops)
     assert nbytes > 0, L.last_error()
-    want = 0
+    # [program ints | small floats (biases padded to 16-wide tiles, affine scale / shift) | packed weights]
+    prog = 16 * len(ops) + 4 * 32          # op descriptors + one sentinel step per wave
+    small = weights = 0
     for op in ops:
         if op.kind == L.POL_DENSE:
             k16, nt = (op.in_dim + 15) // 16, (op.out_dim + 15) // 16
-            want += nt * k16 * 256 + nt * 16
+            weights += nt * k16 * 256
+            small += nt * 16
+            for w in range(4):                                            # per-wave step lists
+                slots = (nt - w + 3) // 4 if w < nt else 0
+                while slots > 0:
+                    u = 4 if slots >= 4 else 2 if slots >= 2 else 1
+                    prog += 32 * ((k16 + 3) // 4)
+                    slots -= u
         elif op.kind == L.POL_AFFINE:
-            want += (2 * op.out_dim + 3) // 4 * 4
-    assert nbytes == 4 * want
+            small += (2 * op.out_dim + 3) // 4 * 4
+    assert nbytes == 4 * (prog + small + weights)
     assert d.n_logits == 8 and blob.dtype == np.float32
     # a program that reads outside its buffer is refused with a message, not run
     bad = type(ops)(*ops)
