@@ -225,6 +225,10 @@ size_t qd_policy_packed_bytes(const qd_policy_desc* desc, const qd_policy_op* op
 int qd_policy_create(const qd_policy_desc* desc, const qd_policy_op* ops, const float* weights_host, size_t n_weights,
                      void* packed_device, size_t packed_bytes, qd_policy** out);
 int qd_policy_destroy(qd_policy* policy);
+/* which kernel serves this policy: 0 = the generic layer-program interpreter, > 0 = a compile-time specialisation for
+ * one of the reference's networks at the training scripts' sizes (same results; selected on an exact program match;
+ * QD_POLICY_GENERIC=1 in the environment forces 0) */
+int qd_policy_kernel(qd_policy* policy);
 /* model.forward + value_function + MyBetaDist.deterministic_sample; any of actions / logits / value may be
  * NULL; prev_actions / prev_truncated may be NULL (= zeros / no episode boundary) */
 int qd_policy_forward(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions,

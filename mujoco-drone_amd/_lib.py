@@ -97,6 +97,7 @@ SIGNATURES = {
     "qd_policy_create": (_I, [C.POINTER(QdPolicyDesc), C.POINTER(QdPolicyOp), _VP, C.c_size_t, _VP, C.c_size_t,
                               C.POINTER(_VP)]),
     "qd_policy_destroy": (_I, [_VP]),
+    "qd_policy_kernel": (_I, [_VP]),
     "qd_policy_forward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),

@@ -31,6 +31,7 @@
 #include "qd_obsrew.h"
 #include "qd_pid.h"
 #include "qd_policy.h"
+#include "qd_policy_static.h"
 #include "qd_rng.h"
 
 namespace qd {

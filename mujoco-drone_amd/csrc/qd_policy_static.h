@@ -1,0 +1,326 @@
+// qd_policy_static.h -- compile-time specialisations of the policy kernel for the reference's actual networks.
+//
+// k_policy (qd_policy.h) interprets any layer program, but with ONE wave per SIMD every interpreted step costs ~500
+// instructions at ~5 cycles each: 1.1 us of bookkeeping around 0.1-0.45 us of MFMAs (measured with the stamped
+// build, tests/diag_policy_stamps.py).  The networks the reference actually trains are fixed (train_PPO.py:39-45:
+// num_states 16, num_params 6, num_actions 4, param_embed_dim 8), so their programs are also compiled into the
+// library as constexpr tables and the same algorithm is instantiated with every size, offset and trip count known at
+// compile time: addresses fold into immediates, layers unroll, and the weights of the next layer's first k-blocks are
+// requested before the current layer's barrier.  qd_policy_create compares the program it is given with these tables
+// and uses the specialisation only on an exact match; both kernels read the same packed blob.
+#pragma once
+
+#include "qd_policy.h"
+
+namespace qd {
+
+struct SOp {
+  int kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act, flags;
+};
+constexpr int SPROG_MAX = 24;
+struct SProg {
+  int n_ops;
+  SOp op[SPROG_MAX];
+  int n_bufs, width[POL_MAX_BUFS];
+  int obs_dim, act_dim;
+  int logits_buf, logits_off, n_logits, value_buf, value_off;
+};
+
+// ---- layout, the same arithmetic as pol_compile (qd_policy_host.inc) ----
+constexpr int sp_w16(const SProg& p, int b) { return (p.width[b] + 15) / 16 * 16; }
+constexpr int sp_ld(const SProg& p, int b) { return sp_w16(p, b) + 4; }
+constexpr int sp_base(const SProg& p, int b) {
+  int off = 0;
+  for (int i = 0; i < b; i++) off += POL_TILE * sp_ld(p, i);
+  return off;
+}
+constexpr int sp_act_floats(const SProg& p) { return sp_base(p, p.n_bufs); }
+constexpr int sp_k16(const SProg& p, int k) { return (p.op[k].in_dim + 15) / 16; }
+constexpr int sp_ntiles(const SProg& p, int k) { return (p.op[k].out_dim + 15) / 16; }
+constexpr long long sp_w_at(const SProg& p, int k) {  // floats, within the weight region
+  long long off = 0;
+  for (int i = 0; i < k; i++)
+    if (p.op[i].kind == POL_DENSE) off += (long long)sp_ntiles(p, i) * sp_k16(p, i) * 256;
+  return off;
+}
+constexpr int sp_s_at(const SProg& p, int k) {  // floats, within the small region
+  int off = 0;
+  for (int i = 0; i < k; i++) {
+    if (p.op[i].kind == POL_DENSE) off += sp_ntiles(p, i) * 16;
+    else if (p.op[i].kind == POL_AFFINE) off += (2 * p.op[i].out_dim + 3) / 4 * 4;
+  }
+  return off;
+}
+constexpr int sp_next_dense(const SProg& p, int from) {
+  for (int i = from; i < p.n_ops; i++)
+    if (p.op[i].kind == POL_DENSE) return i;
+  return p.n_ops;
+}
+constexpr int sp_min(int a, int b) { return a < b ? a : b; }
+
+// ---- the reference's networks with the training scripts' sizes (mirrors mujoco_drone_amd/policy.py) ----
+constexpr int SX = 0, SP = 1, SA = 2, SB = 3, SV = POL_FLAG_VALUE_ONLY, TANH = POL_ACT_TANH;
+struct ArchRmaFull {  // models/PPO/RMA/RMA_model.py:17-110, train_adaptation=False
+  static constexpr SProg prog = {13,
+      {{POL_COPY_OBS, 0, 0, 16, SX, 0, 16, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 16, 4, 0, 0}, {POL_COPY_OBS, 0, 16, 6, SP, 0, 6, 0, 0},
+       {POL_DENSE, SP, 0, 6, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SX, 20, 8, 0, 0},
+       {POL_DENSE, SX, 0, 28, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_AFFINE, SB, 0, 128, SB, 0, 128, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0}, {POL_DENSE, SA, 0, 128, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0};
+};
+struct ArchRmaModel {  // models/PPO/RMA/RMA_model.py:199-292
+  static constexpr SProg prog = {16,
+      {{POL_COPY_OBS, 0, 0, 16, SX, 0, 16, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 16, 4, 0, 0}, {POL_COPY_OBS, 0, 16, 6, SP, 0, 6, 0, 0},
+       {POL_DENSE, SP, 0, 6, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SX, 20, 8, TANH, 0},
+       {POL_DENSE, SX, 0, 28, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0},
+       {POL_DENSE, SA, 0, 128, SB, 0, 96, TANH, 0}, {POL_AFFINE, SB, 0, 96, SB, 0, 96, 0, 0},
+       {POL_DENSE, SB, 0, 96, SA, 0, 64, TANH, 0}, {POL_DENSE, SA, 0, 64, SA, 64, 64, TANH, 0}, {POL_DENSE, SA, 64, 64, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 96, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0};
+};
+struct ArchSimpleMlp {  // models/PPO/SimpleMLP/SimpleMLP.py:18-98
+  static constexpr SProg prog = {22,
+      {{POL_COPY_OBS, 0, 0, 22, SX, 0, 22, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 22, 4, 0, 0}, {POL_AFFINE, SX, 0, 26, SX, 0, 26, 0, 0},
+       {POL_DENSE, SX, 0, 26, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0},
+       {POL_DENSE, SA, 0, 128, SB, 0, 96, TANH, 0}, {POL_AFFINE, SB, 0, 96, SB, 0, 96, 0, 0},
+       {POL_DENSE, SB, 0, 96, SA, 0, 64, TANH, 0}, {POL_DENSE, SA, 0, 64, SA, 128, 64, TANH, 0}, {POL_DENSE, SA, 128, 64, SX, 0, 8, 0, 0},
+       {POL_COPY_OBS, 0, 0, 22, SP, 0, 22, 0, SV}, {POL_COPY_PREV, 0, 0, 4, SP, 22, 4, 0, SV}, {POL_AFFINE, SP, 0, 26, SP, 0, 26, 0, SV},
+       {POL_DENSE, SP, 0, 26, SA, 0, 256, TANH, SV}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, SV}, {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV},
+       {POL_DENSE, SA, 0, 128, SB, 0, 96, TANH, SV}, {POL_AFFINE, SB, 0, 96, SB, 0, 96, 0, SV},
+       {POL_DENSE, SB, 0, 96, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SP, 0, 1, 0, SV}},
+      4, {32, 32, 256, 128}, 22, 4, SX, 0, 8, SP, 0};
+};
+
+// ---- the specialised kernel ----
+struct SCtx {
+  float* lds;
+  const float* small;      // LDS mirror of the small region
+  const float4* weights;   // packed weights + lane
+  const float* obs;
+  const float* prev_actions;
+  const uint8_t* prev_truncated;
+  int n_envs, env0, tid, wave, li, lg;
+  bool want_value;
+};
+
+constexpr int SPF = 8;  // k-blocks of the next dense layer requested before the current layer's barrier
+template <class A, int I> struct SDense {
+  static constexpr int K16 = I < A::prog.n_ops ? sp_k16(A::prog, I) : 1;
+  static constexpr int NT = I < A::prog.n_ops ? sp_ntiles(A::prog, I) : 1;
+  static constexpr int SLOTS = (NT + POL_WAVES - 1) / POL_WAVES;   // tile slots per wave (tile = wave + 4 slot, clamped)
+  static constexpr int U0 = sp_min(SLOTS, 4);                      // tiles of the first group
+  static constexpr int PB = sp_min(K16, SPF);                      // prefetched k-blocks (first group only)
+};
+template <class A, int I> struct SPre {  // prefetched weights of dense op I (empty if I is past the end)
+  float4 w[SDense<A, I>::PB][SDense<A, I>::U0];
+};
+
+template <class A, int I>
+__device__ __forceinline__ const float4* s_tile_ptr(const SCtx& c, int slot) {
+  constexpr int K16 = SDense<A, I>::K16, NT = SDense<A, I>::NT;
+  constexpr long long W4 = I < A::prog.n_ops ? sp_w_at(A::prog, I) / 4 : 0;
+  const int tile = min(c.wave + POL_WAVES * slot, NT - 1);  // waves without a tile in this slot repeat the last one
+  return c.weights + W4 + (size_t)tile * (K16 * 64);
+}
+
+template <class A, int I>
+__device__ __forceinline__ void s_prefetch(const SCtx& c, SPre<A, I>& pre) {
+  if constexpr (I < A::prog.n_ops) {
+#pragma unroll
+    for (int u = 0; u < SDense<A, I>::U0; u++) {
+      const float4* src = s_tile_ptr<A, I>(c, u);
+#pragma unroll
+      for (int kb = 0; kb < SDense<A, I>::PB; kb++) pre.w[kb][u] = src[kb * 64];
+    }
+  }
+}
+
+template <class A, int I>
+__device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int K16 = SDense<A, I>::K16, NT = SDense<A, I>::NT, SLOTS = SDense<A, I>::SLOTS, PB = SDense<A, I>::PB;
+  constexpr int ld_in = sp_ld(A::prog, op.in_buf), ld_out = sp_ld(A::prog, op.out_buf);
+  constexpr int in_base = sp_base(A::prog, op.in_buf) + op.in_off, out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+  constexpr int s_at = sp_s_at(A::prog, I);
+  const float* a_ptr = c.lds + in_base + c.li * ld_in + c.lg * 4;
+  float* o_ptr = c.lds + out_base + (4 * c.lg) * ld_out + c.li;
+  const float* bias = c.small + s_at + c.li;
+#pragma unroll
+  for (int g0 = 0; g0 < SLOTS; g0 += 4) {
+    constexpr int UMAX = 4;
+    const int U = sp_min(SLOTS - g0, UMAX);  // compile-time after unrolling
+    pol_f32x4 acc[UMAX];
+    const float4* wp[UMAX];
+#pragma unroll
+    for (int u = 0; u < UMAX; u++) {
+      if (u < U) {
+        const int tile = min(c.wave + POL_WAVES * (g0 + u), NT - 1);
+        const float b = bias[tile * 16];
+        acc[u] = pol_f32x4{b, b, b, b};
+        wp[u] = s_tile_ptr<A, I>(c, g0 + u);
+      }
+    }
+#pragma unroll
+    for (int kb = 0; kb < K16; kb++) {
+      const float4 a = *reinterpret_cast<const float4*>(a_ptr + kb * 16);
+      float4 w[UMAX];
+#pragma unroll
+      for (int u = 0; u < UMAX; u++)
+        if (u < U) w[u] = (g0 == 0 && kb < PB) ? pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0] : wp[u][kb * 64];
+#pragma unroll
+      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[u].x, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[u].y, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[u].z, acc[u], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[u].w, acc[u], 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < UMAX; u++) {
+      if (u < U) {
+        const int tile = c.wave + POL_WAVES * (g0 + u);
+        if (tile < NT && tile * 16 + c.li < op.out_dim) {
+#pragma unroll
+          for (int v = 0; v < 4; v++) o_ptr[v * ld_out + tile * 16] = pol_act(acc[u][v], op.act);
+        }
+      }
+    }
+  }
+}
+
+template <class A, int I>
+__device__ __forceinline__ void s_other(const SCtx& c) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+  constexpr int s_at = sp_s_at(A::prog, I), obs_dim = A::prog.obs_dim, act_dim = A::prog.act_dim;
+  float* b = c.lds + out_base;
+  if constexpr (op.kind == POL_AFFINE) {
+    constexpr int n = op.out_dim;
+    const float* sc = c.small + s_at;
+    for (int k = c.tid; k < POL_TILE * n; k += POL_THREADS) {
+      const int r = k / n, col = k - r * n;
+      b[r * ld + col] = fmaf(b[r * ld + col], sc[col], sc[n + col]);
+    }
+  } else {
+    constexpr int n = op.in_dim;
+    for (int k = c.tid; k < POL_TILE * n; k += POL_THREADS) {
+      const int r = k / n, col = k - r * n;
+      const int e = c.env0 + r;
+      float v = 0.f;
+      if (e < c.n_envs) {
+        if constexpr (op.kind == POL_COPY_OBS) v = c.obs[(size_t)e * obs_dim + op.in_off + col];
+        else if (c.prev_actions && !(c.prev_truncated && c.prev_truncated[e])) v = c.prev_actions[(size_t)e * act_dim + op.in_off + col];
+      }
+      b[r * ld + col] = v;
+    }
+  }
+}
+
+// ops I.. of the program; `pre` holds the prefetched weights of dense op J = the first dense op at or after I
+template <class A, int I, int J>
+__device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
+  if constexpr (I < A::prog.n_ops) {
+    constexpr SOp op = A::prog.op[I];
+    const bool runs = c.want_value || !(op.flags & POL_FLAG_VALUE_ONLY);  // uniform over the workgroup
+    if constexpr (op.kind == POL_DENSE) {
+      static_assert(I == J, "prefetch bookkeeping");
+      constexpr int JN = sp_next_dense(A::prog, I + 1);
+      SPre<A, JN> next;
+      s_prefetch<A, JN>(c, next);
+      if (runs) {
+        s_dense<A, I>(c, pre);
+        __syncthreads();
+      }
+      s_run<A, I + 1, JN>(c, next);
+    } else {
+      if (runs) {
+        s_other<A, I>(c);
+        __syncthreads();
+      }
+      s_run<A, I + 1, J>(c, pre);
+    }
+  }
+}
+
+template <class A>
+__global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_envs, const float* __restrict__ obs,
+                                                               const float* __restrict__ prev_actions,
+                                                               const uint8_t* __restrict__ prev_truncated, float* __restrict__ actions,
+                                                               float* __restrict__ logits, float* __restrict__ value) {
+  extern __shared__ float lds[];
+  constexpr int ACT = sp_act_floats(A::prog);
+  SCtx c;
+  c.lds = lds; c.small = lds + ACT;
+  c.tid = threadIdx.x; c.wave = c.tid >> 6;
+  const int lane = c.tid & 63;
+  c.li = lane & 15; c.lg = lane >> 4;
+  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
+  c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
+  c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
+  // the first dense layer's weights are requested before anything else
+  constexpr int J0 = sp_next_dense(A::prog, 0);
+  SPre<A, J0> pre;
+  s_prefetch<A, J0>(c, pre);
+  {
+    const float4* src = reinterpret_cast<const float4*>(p.packed + p.prog_ints);
+    float4* dst = reinterpret_cast<float4*>(lds + ACT);
+    for (int k = c.tid; k < (p.small_floats >> 2); k += POL_THREADS) dst[k] = src[k];
+    for (int k = c.tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
+  }
+  __syncthreads();
+  s_run<A, 0, J0>(c, pre);
+  // outputs: logits, MyBetaDist.deterministic_sample (distributions.py:8-26), value
+  constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits, H = NL / 2, AD = A::prog.act_dim;
+  constexpr int lg_base = sp_base(A::prog, A::prog.logits_buf) + A::prog.logits_off;
+  constexpr int VB = A::prog.value_buf < 0 ? 0 : A::prog.value_buf;
+  constexpr int v_base = sp_base(A::prog, VB) + A::prog.value_off, v_ld = sp_ld(A::prog, VB);
+  constexpr bool has_value = A::prog.value_buf >= 0;
+  const float* lgt = lds + lg_base;
+  if (logits)
+    for (int k = c.tid; k < POL_TILE * NL; k += POL_THREADS) {
+      const int r = k / NL, col = k - r * NL;
+      if (c.env0 + r < n_envs) logits[(size_t)(c.env0 + r) * NL + col] = lgt[r * ldl + col];
+    }
+  if (actions)
+    for (int k = c.tid; k < POL_TILE * H; k += POL_THREADS) {
+      const int r = k / H, col = k - r * H;
+      if (c.env0 + r < n_envs) {
+        const float la = qclamp(lgt[r * ldl + col], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + col], -50.f, 50.f);
+        const float al = log1pf(__expf(la)) + 1.0f, be = log1pf(__expf(lb)) + 1.0f;
+        actions[(size_t)(c.env0 + r) * AD + col] = al * __builtin_amdgcn_rcpf(al + be);
+      }
+    }
+  if (has_value && c.want_value && c.tid < POL_TILE && c.env0 + c.tid < n_envs) value[c.env0 + c.tid] = lds[v_base + c.tid * v_ld];
+}
+
+// ---- host: does a program handed to qd_policy_create equal one of the tables above? ----
+template <class A>
+inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
+  const SProg& s = A::prog;
+  if (d->n_ops != s.n_ops || d->n_bufs != s.n_bufs || d->obs_dim != s.obs_dim || d->act_dim != s.act_dim) return false;
+  if (d->logits_buf != s.logits_buf || d->logits_off != s.logits_off || d->n_logits != s.n_logits) return false;
+  if (d->value_buf != s.value_buf || d->value_off != s.value_off) return false;
+  for (int b = 0; b < s.n_bufs; b++)
+    if ((d->buf_width[b] + 15) / 16 != (s.width[b] + 15) / 16) return false;
+  for (int k = 0; k < s.n_ops; k++) {
+    const qd_policy_op& a = ops[k];
+    const SOp& b = s.op[k];
+    if (a.kind != b.kind || a.in_off != b.in_off || a.in_dim != b.in_dim || a.out_buf != b.out_buf || a.out_off != b.out_off ||
+        a.out_dim != b.out_dim || a.act != b.act || a.flags != b.flags)
+      return false;
+    if (a.kind == QD_POL_DENSE && a.in_buf != b.in_buf) return false;
+  }
+  return true;
+}
+inline int pol_arch_of(const qd_policy_desc* d, const qd_policy_op* ops) {
+  const char* e = getenv("QD_POLICY_GENERIC");  // testing: force the interpreter
+  if (e && atoi(e)) return 0;
+  if (pol_matches<ArchRmaFull>(d, ops)) return 1;
+  if (pol_matches<ArchRmaModel>(d, ops)) return 2;
+  if (pol_matches<ArchSimpleMlp>(d, ops)) return 3;
+  return 0;
+}
+
+}  // namespace qd

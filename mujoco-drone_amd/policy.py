@@ -159,6 +159,7 @@ class DevicePolicy:
             L.check(self.lib.qd_policy_create(C.byref(d), ops, blob.ctypes.data_as(C.c_void_p), blob.size, _ptr(self.packed),
                                               nbytes, C.byref(handle)))
         self.handle = handle
+        self.kernel = int(self.lib.qd_policy_kernel(handle))   # 0: generic interpreter, > 0: specialised
         self.n_weights, self.n_ops = int(blob.size), int(d.n_ops)
 
     def __del__(self):

@@ -24,10 +24,22 @@ def weights_of(PG, tag):
     return {k: PG[tag + "/" + k] for k in PG[tag + "_keys"]}
 
 
+@pytest.fixture(params=["specialised", "interpreter"])
+def kernel(request, monkeypatch):
+    """both kernels behind qd_policy_*: the compile-time specialisation the library picks for the reference's networks
+    and the generic layer-program interpreter (forced through QD_POLICY_GENERIC, read at qd_policy_create)"""
+    if request.param == "interpreter":
+        monkeypatch.setenv("QD_POLICY_GENERIC", "1")
+    else:
+        monkeypatch.delenv("QD_POLICY_GENERIC", raising=False)
+    return request.param
+
+
 @pytest.mark.parametrize("tag", list(TAGS))
-def test_policy_forward_vs_reference_models(PG, tag):
+def test_policy_forward_vs_reference_models(PG, tag, kernel):
     from mujoco_drone_amd.policy import DevicePolicy
     pol = DevicePolicy(TAGS[tag], weights_of(PG, tag))
+    assert (pol.kernel > 0) == (kernel == "specialised")
     obs, prev = torch.tensor(PG["obs"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda")
     act, logits, value = pol.forward(obs, prev, want_logits=True, want_value=True)
     np.testing.assert_allclose(logits.cpu().numpy(), PG[tag + "_logits"], atol=2e-5)
@@ -38,7 +50,7 @@ def test_policy_forward_vs_reference_models(PG, tag):
 
 
 @pytest.mark.parametrize("n", [1, 17, 4096 + 5])
-def test_policy_forward_vs_oracle_ragged_batches(PG, n):
+def test_policy_forward_vs_oracle_ragged_batches(PG, n, kernel):
     """batch sizes that are not multiples of the 16-env tile; previous actions absent / zeroed at episode starts"""
     from mujoco_drone_amd.policy import DevicePolicy
     from oracle import policy_ref as P
@@ -60,7 +72,7 @@ def test_policy_forward_vs_oracle_ragged_batches(PG, n):
     np.testing.assert_allclose(a0.cpu().numpy(), P.beta_mean_action(wl0), atol=1e-5)
 
 
-def test_policy_closed_loop_rollout(PG):
+def test_policy_closed_loop_rollout(PG, kernel):
     """qd_rollout_policy == T x (qd_policy_forward, qd_step): observations feed the policy, its actions feed the env and
     come back as prev_actions, zeroed where the env was just re-sampled; and against the float64 oracle policy fed
     with the device's observations"""
@@ -91,3 +103,33 @@ def test_policy_closed_loop_rollout(PG):
     assert int(out["truncated"].sum()) == 3 * 200      # max_steps = 9: every env truncated three times in 30 steps
     with pytest.raises(ValueError):
         pol.rollout(e1._dev, 2, torch.zeros((200, 21), device="cuda"))
+
+
+def test_policy_nonstandard_sizes_use_the_interpreter(PG):
+    """a network whose sizes differ from the training scripts' (param_embed_dim 5, 20 states) has no specialisation: the
+    library falls back to the interpreter, same results as the float64 oracle"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    rng = np.random.default_rng(4)
+    ns, npar, na, emb, D = 20, 6, 4, 5, 26
+
+    def fc(o, i):
+        return (rng.normal(size=(o, i)) / np.sqrt(i)).astype(np.float32), (0.1 * rng.normal(size=o)).astype(np.float32)
+    w = {}
+    for name, (o, i) in {"param_encoder.0": (32, npar), "param_encoder.1": (emb, 32), "_hidden_layers.0": (256, ns + na + emb),
+                         "_hidden_layers.1": (128, 256), "_logits.0": (128, 128), "_logits.1": (8, 128),
+                         "_value_branch.0": (128, 128), "_value_branch.1": (128, 128), "_value_branch.2": (1, 128)}.items():
+        w[name + "._model.0.weight"], w[name + "._model.0.bias"] = fc(o, i)
+    w["_hidden_layers.2.weight"] = rng.uniform(0.5, 1.5, 128).astype(np.float32)
+    w["_hidden_layers.2.bias"] = (0.1 * rng.normal(size=128)).astype(np.float32)
+    w["_hidden_layers.2.running_mean"] = (0.2 * rng.normal(size=128)).astype(np.float32)
+    w["_hidden_layers.2.running_var"] = rng.uniform(0.25, 1.75, 128).astype(np.float32)
+    pol = DevicePolicy("RMA_full", w, obs_dim=D, num_states=ns, num_params=npar, num_actions=na)
+    assert pol.kernel == 0
+    n = 77
+    obs = rng.normal(size=(n, D)).astype(np.float32); prev = rng.uniform(0, 1, (n, na)).astype(np.float32)
+    act, logits, value = pol.forward(torch.tensor(obs, device="cuda"), torch.tensor(prev, device="cuda"), want_logits=True, want_value=True)
+    wl, wv = P.rma_full(w, obs, prev, num_states=ns, num_params=npar)
+    np.testing.assert_allclose(logits.cpu().numpy(), wl, atol=3e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), wv, atol=3e-5)
+    np.testing.assert_allclose(act.cpu().numpy(), P.beta_mean_action(wl), atol=1e-5)
