@@ -57,6 +57,26 @@ constexpr int sp_next_dense(const SProg& p, int from) {
   return p.n_ops;
 }
 constexpr int sp_min(int a, int b) { return a < b ? a : b; }
+// is dense op k directly followed by an affine op on exactly its output slice (tanh -> BatchNorm)?  Then the affine map is
+// applied in the dense layer's epilogue and the op itself is skipped.
+constexpr bool sp_fused_affine(const SProg& p, int k) {
+  return k + 1 < p.n_ops && p.op[k].kind == POL_DENSE && p.op[k + 1].kind == POL_AFFINE && p.op[k + 1].out_buf == p.op[k].out_buf &&
+         p.op[k + 1].out_off == p.op[k].out_off && p.op[k + 1].out_dim == p.op[k].out_dim && p.op[k + 1].flags == p.op[k].flags;
+}
+constexpr int sp_small_floats(const SProg& p) {
+  int off = 0;
+  for (int i = 0; i < p.n_ops; i++) {
+    if (p.op[i].kind == POL_DENSE) off += (p.op[i].out_dim + 15) / 16 * 16;
+    else if (p.op[i].kind == POL_AFFINE) off += (2 * p.op[i].out_dim + 3) / 4 * 4;
+  }
+  return (off + 3) / 4 * 4;
+}
+// leading input gathers (COPY ops before anything else): done in the prologue, under one global-load latency
+constexpr int sp_leading_copies(const SProg& p) {
+  int n = 0;
+  while (n < p.n_ops && (p.op[n].kind == POL_COPY_OBS || p.op[n].kind == POL_COPY_PREV) && !(p.op[n].flags & POL_FLAG_VALUE_ONLY)) n++;
+  return n;
+}
 
 // ---- the reference's networks with the training scripts' sizes (mirrors mujoco_drone_amd/policy.py) ----
 constexpr int SX = 0, SP = 1, SA = 2, SB = 3, SV = POL_FLAG_VALUE_ONLY, TANH = POL_ACT_TANH;
@@ -146,6 +166,8 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   const float* a_ptr = c.lds + in_base + c.li * ld_in + c.lg * 4;
   float* o_ptr = c.lds + out_base + (4 * c.lg) * ld_out + c.li;
   const float* bias = c.small + s_at + c.li;
+  constexpr int aff_at = sp_fused_affine(A::prog, I) ? sp_s_at(A::prog, I + 1) : 0;
+  const float* aff = c.small + aff_at + c.li;  // scale at [col], shift at [out_dim + col] of the affine op that follows
 #pragma unroll
   for (int g0 = 0; g0 < SLOTS; g0 += 4) {
     constexpr int UMAX = 4;
@@ -183,7 +205,11 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
         const int tile = c.wave + POL_WAVES * (g0 + u);
         if (tile < NT && tile * 16 + c.li < op.out_dim) {
 #pragma unroll
-          for (int v = 0; v < 4; v++) o_ptr[v * ld_out + tile * 16] = pol_act(acc[u][v], op.act);
+          for (int v = 0; v < 4; v++) {
+            float y = pol_act(acc[u][v], op.act);
+            if constexpr (sp_fused_affine(A::prog, I)) y = fmaf(y, aff[tile * 16], aff[op.out_dim + tile * 16]);  // eval-mode BatchNorm
+            o_ptr[v * ld_out + tile * 16] = y;
+          }
         }
       }
     }
@@ -218,6 +244,50 @@ __device__ __forceinline__ void s_other(const SCtx& c) {
   }
 }
 
+template <class A, int I> struct SCopy {
+  static constexpr int N = A::prog.op[I < A::prog.n_ops ? I : 0].in_dim;
+  static constexpr int IT = (POL_TILE * N + POL_THREADS - 1) / POL_THREADS;
+  float v[IT];
+};
+template <class A, int I>
+__device__ __forceinline__ void s_copy_load(const SCtx& c, SCopy<A, I>& r) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int n = op.in_dim, obs_dim = A::prog.obs_dim, act_dim = A::prog.act_dim;
+#pragma unroll
+  for (int it = 0; it < SCopy<A, I>::IT; it++) {
+    const int k = c.tid + it * POL_THREADS;
+    const int row = k / n, col = k - row * n, e = c.env0 + row;
+    float v = 0.f;
+    if (k < POL_TILE * n && e < c.n_envs) {
+      if constexpr (op.kind == POL_COPY_OBS) v = c.obs[(size_t)e * obs_dim + op.in_off + col];
+      else if (c.prev_actions && !(c.prev_truncated && c.prev_truncated[e])) v = c.prev_actions[(size_t)e * act_dim + op.in_off + col];
+    }
+    r.v[it] = v;
+  }
+}
+template <class A, int I>
+__device__ __forceinline__ void s_copy_store(const SCtx& c, const SCopy<A, I>& r) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int n = op.in_dim, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+#pragma unroll
+  for (int it = 0; it < SCopy<A, I>::IT; it++) {
+    const int k = c.tid + it * POL_THREADS;
+    const int row = k / n, col = k - row * n;
+    if (k < POL_TILE * n) c.lds[out_base + row * ld + col] = r.v[it];
+  }
+}
+// the first LC ops are input gathers: all their loads are issued together (with the small region's) in the prologue
+template <class A, int I, int LC> struct SLead {
+  SCopy<A, I> cur;
+  SLead<A, I + 1, LC> rest;
+  __device__ __forceinline__ void load(const SCtx& c) { s_copy_load<A, I>(c, cur); rest.load(c); }
+  __device__ __forceinline__ void store(const SCtx& c) const { s_copy_store<A, I>(c, cur); rest.store(c); }
+};
+template <class A, int LC> struct SLead<A, LC, LC> {
+  __device__ __forceinline__ void load(const SCtx&) {}
+  __device__ __forceinline__ void store(const SCtx&) const {}
+};
+
 // ops I.. of the program; `pre` holds the prefetched weights of dense op J = the first dense op at or after I
 template <class A, int I, int J>
 __device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
@@ -232,12 +302,17 @@ __device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
       if (runs) {
         s_dense<A, I>(c, pre);
         __syncthreads();
+        POL_STAMP(2 + I);
       }
       s_run<A, I + 1, JN>(c, next);
     } else {
-      if (runs) {
-        s_other<A, I>(c);
-        __syncthreads();
+      constexpr bool fused = I > 0 && sp_fused_affine(A::prog, I > 0 ? I - 1 : 0);  // already applied by the dense op before it
+      if constexpr (!fused) {
+        if (runs) {
+          s_other<A, I>(c);
+          __syncthreads();
+          POL_STAMP(2 + I);
+        }
       }
       s_run<A, I + 1, J>(c, pre);
     }
@@ -261,16 +336,37 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
   // the first dense layer's weights are requested before anything else
   constexpr int J0 = sp_next_dense(A::prog, 0);
+  POL_STAMP(0);
   SPre<A, J0> pre;
   s_prefetch<A, J0>(c, pre);
+  // prologue: every global read that does not depend on the network (biases / affine parameters, the leading input
+  // gathers) is issued at once, LDS is cleared under their latency, then they are written behind one barrier
+  constexpr int LC = sp_leading_copies(A::prog), S4 = sp_small_floats(A::prog) / 4, SIT = (S4 + POL_THREADS - 1) / POL_THREADS;
+  float4 sm[SIT];
   {
     const float4* src = reinterpret_cast<const float4*>(p.packed + p.prog_ints);
-    float4* dst = reinterpret_cast<float4*>(lds + ACT);
-    for (int k = c.tid; k < (p.small_floats >> 2); k += POL_THREADS) dst[k] = src[k];
-    for (int k = c.tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
+#pragma unroll
+    for (int it = 0; it < SIT; it++) {
+      const int k = c.tid + it * POL_THREADS;
+      sm[it] = k < S4 ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
+  SLead<A, 0, LC> lead;
+  lead.load(c);
+  for (int k = c.tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
   __syncthreads();
-  s_run<A, 0, J0>(c, pre);
+  {
+    float4* dst = reinterpret_cast<float4*>(lds + ACT);
+#pragma unroll
+    for (int it = 0; it < SIT; it++) {
+      const int k = c.tid + it * POL_THREADS;
+      if (k < S4) dst[k] = sm[it];
+    }
+  }
+  lead.store(c);
+  __syncthreads();
+  POL_STAMP(1);
+  s_run<A, LC, J0>(c, pre);
   // outputs: logits, MyBetaDist.deterministic_sample (distributions.py:8-26), value
   constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits, H = NL / 2, AD = A::prog.act_dim;
   constexpr int lg_base = sp_base(A::prog, A::prog.logits_buf) + A::prog.logits_off;
@@ -288,11 +384,12 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
       const int r = k / H, col = k - r * H;
       if (c.env0 + r < n_envs) {
         const float la = qclamp(lgt[r * ldl + col], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + col], -50.f, 50.f);
-        const float al = log1pf(__expf(la)) + 1.0f, be = log1pf(__expf(lb)) + 1.0f;
+        const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
         actions[(size_t)(c.env0 + r) * AD + col] = al * __builtin_amdgcn_rcpf(al + be);
       }
     }
   if (has_value && c.want_value && c.tid < POL_TILE && c.env0 + c.tid < n_envs) value[c.env0 + c.tid] = lds[v_base + c.tid * v_ld];
+  POL_STAMP(2 + A::prog.n_ops);
 }
 
 // ---- host: does a program handed to qd_policy_create equal one of the tables above? ----
