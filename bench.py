@@ -359,6 +359,30 @@ def main():
                         e3._dev.rollout_pid(256)
                     torch.cuda.synchronize()
                     extras["pid_closed_loop_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
+                if args.config == "config3":
+                    # the reference's actor (RMA_full, train_PPO.py:39-45, random-init weights) inside the loop:
+                    # policy forward (f32 MFMA) -> env step, 2 launches per step enqueued by one C call, nothing leaves the GPU
+                    from mujoco_drone_amd.policy import DevicePolicy, random_weights
+                    pol = DevicePolicy("RMA_full", random_weights("RMA_full", 3), device=device)
+                    o3 = e3.vector_reset_tensor().clone()
+                    pa = torch.empty((n, 4), device=device)
+                    for _ in range(20):
+                        pol.forward(o3, out=pa)
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(200):
+                        pol.forward(o3, out=pa)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    extras["policy_forward_us"] = ev0.elapsed_time(ev1) * 1000.0 / 200
+                    extras["policy_forward_TFLOPs"] = 2 * 57792 * n / (extras["policy_forward_us"] * 1e-6) / 1e12
+                    pol.rollout(e3._dev, 64, o3)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    pol.rollout(e3._dev, 1024, o3)
+                    torch.cuda.synchronize()
+                    extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
+                    extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
                 other = "config2" if args.config != "config2" else "config3"
                 e4, alg4 = make_env(other, n, 5, device)
                 (e4.vector_reset_tensor() if other == "config3" else e4.reset())

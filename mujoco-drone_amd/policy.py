@@ -137,6 +137,48 @@ def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, nu
     return d, ops, np.concatenate(prog.blob).astype(np.float32)
 
 
+def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, param_embed_dim=8, num_outputs=8):
+    """random-init state dict of one of the reference's networks (Xavier-normal weights as the reference initialises them,
+    small random biases, non-trivial BatchNorm statistics): for benchmarks and smoke tests, where no checkpoint exists"""
+    rng = np.random.default_rng(seed)
+    w = {}
+
+    def fc(name, i, o):
+        w[name + "._model.0.weight"] = (rng.normal(size=(o, i)) * np.sqrt(2.0 / (i + o))).astype(np.float32)
+        w[name + "._model.0.bias"] = (0.1 * rng.normal(size=o)).astype(np.float32)
+
+    def bn(name, n):
+        w[name + ".weight"] = rng.uniform(0.5, 1.5, n).astype(np.float32)
+        w[name + ".bias"] = (0.1 * rng.normal(size=n)).astype(np.float32)
+        w[name + ".running_mean"] = (0.2 * rng.normal(size=n)).astype(np.float32)
+        w[name + ".running_var"] = rng.uniform(0.25, 1.75, n).astype(np.float32)
+
+    h_in = num_states + num_actions + param_embed_dim
+    if family == "RMA_full":
+        fc("param_encoder.0", num_params, 32); fc("param_encoder.1", 32, param_embed_dim)
+        fc("_hidden_layers.0", h_in, 256); fc("_hidden_layers.1", 256, 128); bn("_hidden_layers.2", 128)
+        fc("_logits.0", 128, 128); fc("_logits.1", 128, num_outputs)
+        fc("_value_branch.0", 128, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+    elif family == "RMA_model":
+        fc("param_encoder.0", num_params, 32); fc("param_encoder.1", 32, param_embed_dim)
+        for k, (i, o) in enumerate(((h_in, 256), (256, 128), (128, 128), (128, 96))):
+            fc("_hidden_layers.%d" % k, i, o)
+        bn("_hidden_layers.4", 96)
+        fc("_logits.0", 96, 64); fc("_logits.1", 64, 64); fc("_logits.2", 64, num_outputs)
+        fc("_value_branch.0", 96, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+    elif family == "SimpleMLPmodel":
+        x = num_states + num_params + num_actions
+        for trunk, tail in (("_logits", (64, 64, num_outputs)), ("_value_branch", (128, 128, 1))):
+            bn(trunk + ".0", x)
+            for k, (i, o) in enumerate(((x, 256), (256, 128), (128, 128), (128, 96))):
+                fc("%s.%d" % (trunk, k + 1), i, o)
+            bn(trunk + ".5", 96)
+            fc(trunk + ".6", 96, tail[0]); fc(trunk + ".7", tail[0], tail[1]); fc(trunk + ".8", tail[1], tail[2])
+    else:
+        raise ValueError("unknown policy family %r" % (family,))
+    return w
+
+
 class DevicePolicy:
     """One of the reference's policy networks, resident on the GPU.
 
