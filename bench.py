@@ -382,6 +382,10 @@ def main():
                     pol.rollout(e3._dev, 1024, o3)
                     torch.cuda.synchronize()
                     extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
+                    t1 = time.perf_counter()
+                    pol.rollout(e3._dev, 1024, o3, explore=True, seed=42, want_logp=True, want_value=True)
+                    torch.cuda.synchronize()
+                    extras["policy_sample_batch_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)  # sampled actions + logp + value
                     extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
                 other = "config2" if args.config != "config2" else "config3"
                 e4, alg4 = make_env(other, n, 5, device)

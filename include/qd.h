@@ -233,12 +233,22 @@ int qd_policy_kernel(qd_policy* policy);
  * NULL; prev_actions / prev_truncated may be NULL (= zeros / no episode boundary) */
 int qd_policy_forward(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions,
                       const uint8_t* prev_truncated, float* actions, float* logits, float* value, void* stream);
-/* T closed-loop steps policy -> vector_step enqueued by one call (2 launches per step, no host round trip):
- * obs0[N,D] is the observation the first action is computed from, prev_actions0[N,4] (nullable) the action
- * before it; obs[T,N,D], actions[T,N,4], reward[T,N], truncated[T,N], logits[T,N,n_logits] / value[T,N] nullable.
- * Same results as T x (qd_policy_forward, qd_step). */
-int qd_rollout_policy(qd_env* env, qd_policy* policy, int T, const float* obs0, const float* prev_actions0, float* obs,
-                      float* actions, float* reward, uint8_t* truncated, float* logits, float* value, void* stream);
+/* the same forward pass with the action taken as RLlib takes it from MyBetaDist (distributions.py:6-38):
+ * explore == 0: deterministic_sample (the Beta mean); explore != 0: a Beta(alpha, beta) draw (TorchBeta.sample; Philox4x32-10
+ * stream keyed by `seed`, one stream per (env, counter, action dimension): pass the step number as `counter`);
+ * logp[N] (nullable) = MyBetaDist.logp(action) = sum over dimensions of log Beta(clamp(a, 0.01, 0.99); alpha, beta) -- the
+ * action_logp PPO stores next to the sample.  logits / value nullable as above. */
+int qd_policy_act(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions, const uint8_t* prev_truncated,
+                  int explore, uint64_t seed, uint32_t counter, float* actions, float* logp, float* logits, float* value,
+                  void* stream);
+/* T closed-loop steps policy -> vector_step enqueued by one call (2 launches per step, no host round trip): what a rollout
+ * worker's sampling loop does (rollout.py:64-85, RLlib's sampler): obs0[N,D] is the observation the first action is computed
+ * from, prev_actions0[N,4] (nullable) the action before it; step t uses counter0 + t.  Outputs obs[T,N,D], actions[T,N,4],
+ * reward[T,N], truncated[T,N] and, nullable, logp[T,N], logits[T,N,n_logits], value[T,N] -- the columns of a PPO sample
+ * batch.  Same results as T x (qd_policy_act, qd_step). */
+int qd_rollout_policy(qd_env* env, qd_policy* policy, int T, const float* obs0, const float* prev_actions0, int explore,
+                      uint64_t seed, uint32_t counter0, float* obs, float* actions, float* reward, uint8_t* truncated,
+                      float* logp, float* logits, float* value, void* stream);
 
 /* _get_obs() on the current simulator state, obs[N,D] */
 int qd_observe(qd_env* env, float* obs, void* stream);

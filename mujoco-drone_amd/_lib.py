@@ -99,7 +99,8 @@ SIGNATURES = {
     "qd_policy_destroy": (_I, [_VP]),
     "qd_policy_kernel": (_I, [_VP]),
     "qd_policy_forward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_policy_act": (_I, [_VP, _I, _VP, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
+    "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),
     "qd_drone_states": (_I, [_VP, _VP, _VP]),
     "qd_eval_obs": (_I, [_I, _I, _VP, _D4, _VP, _I, _VP]),

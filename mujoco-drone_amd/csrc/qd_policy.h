@@ -21,10 +21,11 @@
 #pragma once
 
 #include "qd_math.h"
+#include "qd_policy_dist.h"
 
 namespace qd {
 
-constexpr int POL_MAX_OPS = 24, POL_MAX_BUFS = 4, POL_TILE = 16, POL_THREADS = 256, POL_WAVES = POL_THREADS / 64;
+constexpr int POL_MAX_OPS = 24, POL_MAX_BUFS = 4, POL_WAVES = POL_THREADS / 64;  // POL_TILE, POL_THREADS: qd_policy_dist.h
 constexpr int POL_KC = 4;       // k-blocks (of 16 inputs) per step
 constexpr int POL_DESC = 16;    // ints per op descriptor
 constexpr int POL_SDESC = 32;   // ints per step descriptor
@@ -47,7 +48,7 @@ struct PolArgs {
   int small_floats;           // biases, affine scale / shift
   int n_ops;
   int step_base[POL_WAVES];   // int offset of each wave's step list in the program
-  int act_floats;             // activation buffers (LDS), zero-initialised
+  int act_floats;             // activation buffers + POL_SCRATCH floats (LDS), zero-initialised
   int obs_dim, act_dim;
   int logits_lds, ld_logits, n_logits;   // LDS float offset of env row 0's logits, row stride
   int value_lds, ld_value;               // value_lds < 0: the program has no value head
@@ -150,7 +151,8 @@ __device__ __forceinline__ void pol_mac(const PolStep& s, const PolBuf& w, const
 
 __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, const float* __restrict__ obs,
                                                         const float* __restrict__ prev_actions,
-                                                        const uint8_t* __restrict__ prev_truncated, float* __restrict__ actions,
+                                                        const uint8_t* __restrict__ prev_truncated, PolSample smp,
+                                                        float* __restrict__ actions, float* __restrict__ logp,
                                                         float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -239,26 +241,9 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
     __syncthreads();
     POL_STAMP(2 + o);
   }
-  // outputs: logits, MyBetaDist.deterministic_sample (distributions.py:8-26), value
-  const float* lgt = lds + p.logits_lds;
-  const int ldl = p.ld_logits;
-  if (logits)
-    for (int k = tid; k < POL_TILE * p.n_logits; k += POL_THREADS) {
-      const int r = k / p.n_logits, c = k - r * p.n_logits;
-      if (env0 + r < n_envs) logits[(size_t)(env0 + r) * p.n_logits + c] = lgt[r * ldl + c];
-    }
-  if (actions) {
-    const int h = p.n_logits >> 1;
-    for (int k = tid; k < POL_TILE * h; k += POL_THREADS) {
-      const int r = k / h, c = k - r * h;
-      if (env0 + r < n_envs) {
-        const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + h + c], -50.f, 50.f);
-        const float al = log1pf(__expf(la)) + 1.0f, be = log1pf(__expf(lb)) + 1.0f;
-        actions[(size_t)(env0 + r) * p.act_dim + c] = al * __builtin_amdgcn_rcpf(al + be);
-      }
-    }
-  }
+  // outputs: value, then logits / action / log-prob (MyBetaDist, qd_policy_dist.h)
   if (want_value && p.value_lds >= 0 && tid < POL_TILE && env0 + tid < n_envs) value[env0 + tid] = lds[p.value_lds + tid * p.ld_value];
+  pol_outputs(lds + p.logits_lds, p.ld_logits, p.n_logits, p.act_dim, env0, n_envs, tid, lds + p.act_floats - POL_SCRATCH, smp, actions, logp, logits);
   POL_STAMP(2 + p.n_ops);
 }
 

@@ -1,0 +1,97 @@
+// qd_policy_dist.h -- the output stage shared by both policy kernels: MyBetaDist (distributions.py:6-38) on the logits.
+//   inputs  = softplus(clamp(logits, -50, 50)) + 1, first half alpha (concentration1), second half beta (:12-17)
+//   deterministic_sample = alpha / (alpha + beta)                                                     (:24-26)
+//   sample               = Beta(alpha, beta) draw (TorchBeta.sample -> torch.distributions.Beta.sample, no squashing)
+//   logp(x)              = sum_d log Beta(clamp(x_d, 0.01, 0.99); alpha_d, beta_d)                    (:19-22)
+// The reference draws from torch's global generator; here every (env, step counter, action dimension) has its own
+// Philox4x32-10 stream keyed by the caller's seed (as for resets, qd_rng.h), so a rollout is reproducible whatever the
+// scheduling.  Beta(a, b) = Ga / (Ga + Gb) with Marsaglia-Tsang gamma variates; both shapes are >= 1 by construction
+// (softplus + 1), so the shape-boost step for a < 1 is never needed.
+#pragma once
+
+#include "qd_rng.h"
+
+namespace qd {
+
+constexpr uint32_t STREAM_POLICY = 3u;
+constexpr int POL_TILE = 16, POL_THREADS = 256;  // envs per workgroup (the MFMA M tile), threads per workgroup
+constexpr int POL_SCRATCH = 64;  // floats reserved behind the activation buffers for the per-env log-prob reduction
+
+struct PolSample {
+  int explore;             // 0: deterministic_sample, 1: sample
+  unsigned int counter;    // the caller's step counter: one stream per (env, counter, action dimension)
+  unsigned long long seed;
+};
+
+// log Gamma(z) for z >= 1: recurrence up to z >= 8, then Stirling's series (float32: abs error ~2e-6 for z <= 60)
+__device__ __forceinline__ float pol_lgamma(float z) {
+  float p = 1.0f;
+#pragma unroll
+  for (int k = 0; k < 7; k++) {
+    const bool low = z < 8.0f;
+    p = low ? p * z : p;
+    z = low ? z + 1.0f : z;
+  }
+  const float r = __builtin_amdgcn_rcpf(z), r2 = r * r;
+  const float series = r * fmaf(r2, fmaf(r2, 7.9365079365e-4f, -2.7777777778e-3f), 8.3333333333e-2f);
+  return fmaf(z - 0.5f, __logf(z), -z) + 0.91893853320467274f + series - __logf(p);
+}
+
+// Gamma(a, 1), a >= 1 (Marsaglia & Tsang 2000); `sub` separates the streams of the two variates of one Beta draw
+__device__ __forceinline__ float pol_gamma(float a, const PolSample& s, uint32_t env, uint32_t sub) {
+  const float d = a - 0.33333333333f, c = __builtin_amdgcn_rsqf(9.0f * d);
+  const uint32_t k0 = (uint32_t)s.seed, k1 = (uint32_t)(s.seed >> 32);
+  for (uint32_t attempt = 0; attempt < 16; attempt++) {  // acceptance > 95 % per attempt
+    uint32_t w[4];
+    philox4x32_10(env, s.counter, sub * 16u + attempt, STREAM_POLICY, k0, k1, w);
+    const float u1 = u32_to_unit(w[0]), u2 = u32_to_unit(w[1]), u = u32_to_unit(w[2]);
+    const float z = __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+    float v = fmaf(c, z, 1.0f);
+    if (v <= 0.f) continue;
+    v = v * v * v;
+    if (__logf(u) < fmaf(0.5f * z, z, d - d * v + d * __logf(v))) return d * v;
+  }
+  return d;
+}
+
+// logits (LDS rows lgt[r * ldl + c]) -> actions / logp / logits in global memory for the workgroup's POL_TILE envs.
+// `scratch` = POL_SCRATCH floats of LDS nobody else uses; every thread of the workgroup must call this (it has a barrier).
+__device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, int AD, int env0, int n_envs, int tid, float* scratch,
+                                            const PolSample& smp, float* __restrict__ actions, float* __restrict__ logp,
+                                            float* __restrict__ logits) {
+  if (logits)
+    for (int k = tid; k < POL_TILE * NL; k += POL_THREADS) {
+      const int r = k / NL, c = k - r * NL;
+      if (env0 + r < n_envs) logits[(size_t)(env0 + r) * NL + c] = lgt[r * ldl + c];
+    }
+  const int H = NL >> 1;
+  if (actions || logp) {
+    for (int k = tid; k < POL_TILE * H; k += POL_THREADS) {
+      const int r = k / H, c = k - r * H;
+      const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + c], -50.f, 50.f);
+      const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
+      float x;
+      if (smp.explore) {
+        const float ga = pol_gamma(al, smp, (uint32_t)(env0 + r), 2u * c), gb = pol_gamma(be, smp, (uint32_t)(env0 + r), 2u * c + 1u);
+        x = ga * __builtin_amdgcn_rcpf(ga + gb);
+      } else {
+        x = al * __builtin_amdgcn_rcpf(al + be);
+      }
+      if (actions && env0 + r < n_envs) actions[(size_t)(env0 + r) * AD + c] = x;
+      if (logp && H <= POL_SCRATCH / POL_TILE) {
+        const float xc = qclamp(x, 0.01f, 0.99f);
+        scratch[r * H + c] = (al - 1.0f) * __logf(xc) + (be - 1.0f) * __logf(1.0f - xc) - (pol_lgamma(al) + pol_lgamma(be) - pol_lgamma(al + be));
+      }
+    }
+  }
+  if (logp) {  // uniform over the workgroup
+    __syncthreads();
+    if (tid < POL_TILE && env0 + tid < n_envs) {
+      float sum = 0.f;
+      for (int c = 0; c < H; c++) sum += scratch[tid * H + c];
+      logp[env0 + tid] = sum;
+    }
+  }
+}
+
+}  // namespace qd

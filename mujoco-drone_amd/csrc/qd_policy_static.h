@@ -34,7 +34,7 @@ constexpr int sp_base(const SProg& p, int b) {
   for (int i = 0; i < b; i++) off += POL_TILE * sp_ld(p, i);
   return off;
 }
-constexpr int sp_act_floats(const SProg& p) { return sp_base(p, p.n_bufs); }
+constexpr int sp_act_floats(const SProg& p) { return sp_base(p, p.n_bufs) + POL_SCRATCH; }
 constexpr int sp_k16(const SProg& p, int k) { return (p.op[k].in_dim + 15) / 16; }
 constexpr int sp_ntiles(const SProg& p, int k) { return (p.op[k].out_dim + 15) / 16; }
 constexpr long long sp_w_at(const SProg& p, int k) {  // floats, within the weight region
@@ -322,7 +322,8 @@ __device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
 template <class A>
 __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_envs, const float* __restrict__ obs,
                                                                const float* __restrict__ prev_actions,
-                                                               const uint8_t* __restrict__ prev_truncated, float* __restrict__ actions,
+                                                               const uint8_t* __restrict__ prev_truncated, PolSample smp,
+                                                               float* __restrict__ actions, float* __restrict__ logp,
                                                                float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ float lds[];
   constexpr int ACT = sp_act_floats(A::prog);
@@ -367,28 +368,14 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   __syncthreads();
   POL_STAMP(1);
   s_run<A, LC, J0>(c, pre);
-  // outputs: logits, MyBetaDist.deterministic_sample (distributions.py:8-26), value
-  constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits, H = NL / 2, AD = A::prog.act_dim;
+  // outputs: value, then logits / action / log-prob (MyBetaDist, qd_policy_dist.h)
+  constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits, AD = A::prog.act_dim;
   constexpr int lg_base = sp_base(A::prog, A::prog.logits_buf) + A::prog.logits_off;
   constexpr int VB = A::prog.value_buf < 0 ? 0 : A::prog.value_buf;
   constexpr int v_base = sp_base(A::prog, VB) + A::prog.value_off, v_ld = sp_ld(A::prog, VB);
   constexpr bool has_value = A::prog.value_buf >= 0;
-  const float* lgt = lds + lg_base;
-  if (logits)
-    for (int k = c.tid; k < POL_TILE * NL; k += POL_THREADS) {
-      const int r = k / NL, col = k - r * NL;
-      if (c.env0 + r < n_envs) logits[(size_t)(c.env0 + r) * NL + col] = lgt[r * ldl + col];
-    }
-  if (actions)
-    for (int k = c.tid; k < POL_TILE * H; k += POL_THREADS) {
-      const int r = k / H, col = k - r * H;
-      if (c.env0 + r < n_envs) {
-        const float la = qclamp(lgt[r * ldl + col], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + col], -50.f, 50.f);
-        const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
-        actions[(size_t)(c.env0 + r) * AD + col] = al * __builtin_amdgcn_rcpf(al + be);
-      }
-    }
   if (has_value && c.want_value && c.tid < POL_TILE && c.env0 + c.tid < n_envs) value[c.env0 + c.tid] = lds[v_base + c.tid * v_ld];
+  pol_outputs(lds + lg_base, ldl, NL, AD, c.env0, n_envs, c.tid, lds + ACT - POL_SCRATCH, smp, actions, logp, logits);
   POL_STAMP(2 + A::prog.n_ops);
 }
 

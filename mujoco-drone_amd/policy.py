@@ -220,36 +220,43 @@ class DevicePolicy:
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
 
-    def forward(self, obs, prev_actions=None, prev_truncated=None, want_logits=False, want_value=False, out=None):
-        """model.forward + MyBetaDist.deterministic_sample [+ value_function] for obs [N,D]: actions [N,4]
-        (, logits [N,8], value [N])"""
+    def forward(self, obs, prev_actions=None, prev_truncated=None, want_logits=False, want_value=False, out=None,
+                explore=False, seed=0, counter=0, want_logp=False):
+        """model.forward + the action RLlib takes from MyBetaDist [+ value_function] for obs [N,D]:
+        actions [N,4] (, logp [N]) (, logits [N,8]) (, value [N]).  explore=False: deterministic_sample (the Beta mean);
+        explore=True: a Beta draw from the Philox stream (seed, counter)."""
         n = int(obs.shape[0])
         obs = self._f32(obs, (n, self.obs_dim))
         prev = self._f32(prev_actions, (n, self.act_dim)) if prev_actions is not None else None
         tr = prev_truncated.to(device=self.device, dtype=torch.uint8).contiguous() if prev_truncated is not None else None
         kw = dict(dtype=torch.float32, device=self.device)
         actions = torch.empty((n, self.act_dim), **kw) if out is None else out
+        logp = torch.empty((n,), **kw) if want_logp else None
         logits = torch.empty((n, self.n_logits), **kw) if want_logits else None
         value = torch.empty((n,), **kw) if want_value else None
-        L.check(self.lib.qd_policy_forward(self.handle, n, _ptr(obs), _ptr(prev), _ptr(tr), _ptr(actions), _ptr(logits),
-                                           _ptr(value), self._stream()))
-        res = (actions,) + ((logits,) if want_logits else ()) + ((value,) if want_value else ())
+        L.check(self.lib.qd_policy_act(self.handle, n, _ptr(obs), _ptr(prev), _ptr(tr), int(bool(explore)), int(seed) & (2 ** 64 - 1),
+                                       int(counter) & 0xFFFFFFFF, _ptr(actions), _ptr(logp), _ptr(logits), _ptr(value), self._stream()))
+        res = (actions,) + ((logp,) if want_logp else ()) + ((logits,) if want_logits else ()) + ((value,) if want_value else ())
         return res[0] if len(res) == 1 else res
 
-    def rollout(self, env, T, obs0, prev_actions0=None, want_logits=False, want_value=False):
+    def rollout(self, env, T, obs0, prev_actions0=None, want_logits=False, want_value=False, explore=False, seed=0, counter0=0,
+                want_logp=False):
         """T closed-loop steps policy -> vector_step on a DeviceEnv, enqueued by one call:
-        dict(obs [T,N,D], actions [T,N,4], reward [T,N], truncated [T,N][, logits, value])"""
+        dict(obs [T,N,D], actions [T,N,4], reward [T,N], truncated [T,N][, logp, logits, value]) -- a PPO sample batch"""
         T, n = int(T), env.n
         kw = dict(dtype=torch.float32, device=self.device)
         obs0 = self._f32(obs0, (n, env.D))
         prev = self._f32(prev_actions0, (n, 4)) if prev_actions0 is not None else None
         out = dict(obs=torch.empty((T, n, env.D), **kw), actions=torch.empty((T, n, 4), **kw),
                    reward=torch.empty((T, n), **kw), truncated=torch.empty((T, n), dtype=torch.uint8, device=self.device))
+        if want_logp:
+            out["logp"] = torch.empty((T, n), **kw)
         if want_logits:
             out["logits"] = torch.empty((T, n, self.n_logits), **kw)
         if want_value:
             out["value"] = torch.empty((T, n), **kw)
-        L.check(self.lib.qd_rollout_policy(env.handle, self.handle, T, _ptr(obs0), _ptr(prev), _ptr(out["obs"]),
-                                           _ptr(out["actions"]), _ptr(out["reward"]), _ptr(out["truncated"]),
-                                           _ptr(out.get("logits")), _ptr(out.get("value")), self._stream()))
+        L.check(self.lib.qd_rollout_policy(env.handle, self.handle, T, _ptr(obs0), _ptr(prev), int(bool(explore)),
+                                           int(seed) & (2 ** 64 - 1), int(counter0) & 0xFFFFFFFF, _ptr(out["obs"]), _ptr(out["actions"]),
+                                           _ptr(out["reward"]), _ptr(out["truncated"]), _ptr(out.get("logp")), _ptr(out.get("logits")),
+                                           _ptr(out.get("value")), self._stream()))
         return out

@@ -133,3 +133,64 @@ def test_policy_nonstandard_sizes_use_the_interpreter(PG):
     np.testing.assert_allclose(logits.cpu().numpy(), wl, atol=3e-5)
     np.testing.assert_allclose(value.cpu().numpy(), wv, atol=3e-5)
     np.testing.assert_allclose(act.cpu().numpy(), P.beta_mean_action(wl), atol=1e-5)
+
+
+def test_policy_logp_and_beta_sampling(PG, kernel):
+    """qd_policy_act: MyBetaDist.logp of the action it returns (deterministic and sampled) against the oracle's logp (pinned
+    by the reference's MyBetaDist), and the sampled actions' distribution against Beta(alpha, beta): moments, a
+    Kolmogorov-Smirnov distance per action dimension, reproducibility per (seed, counter)."""
+    from scipy import stats
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    w = weights_of(PG, "rma_full")
+    pol = DevicePolicy("RMA_full", w)
+    obs, prev = torch.tensor(PG["obs"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda")
+    act, logp, logits = pol.forward(obs, prev, want_logp=True, want_logits=True)
+    np.testing.assert_allclose(act.cpu().numpy(), PG["rma_full_action"], atol=1e-5)
+    np.testing.assert_allclose(logp.cpu().numpy(), PG["rma_full_logp"], atol=2e-4)          # the reference's own logp
+    # sampling: one observation repeated, so every row draws from the same four Beta distributions
+    n = 16384
+    o1, p1 = obs[3:4].repeat(n, 1).contiguous(), prev[3:4].repeat(n, 1).contiguous()
+    a, lp, lg = pol.forward(o1, p1, explore=True, seed=11, counter=5, want_logp=True, want_logits=True)
+    a, lp, lg = a.cpu().numpy().astype(np.float64), lp.cpu().numpy(), lg.cpu().numpy().astype(np.float64)
+    assert a.min() > 0.0 and a.max() < 1.0
+    np.testing.assert_allclose(lp, P.beta_logp(lg, a), atol=5e-4)
+    al, be = P.beta_params(lg[0])
+    mean, var = al / (al + be), al * be / ((al + be) ** 2 * (al + be + 1))
+    np.testing.assert_allclose(a.mean(0), mean, atol=5 * np.sqrt(var / n).max())
+    np.testing.assert_allclose(a.var(0), var, rtol=0.06)
+    for d in range(4):
+        ks = stats.kstest(a[:, d], stats.beta(al[d], be[d]).cdf).statistic
+        assert ks < 1.63 / np.sqrt(n), (d, ks)                                           # 1 % level
+    assert abs(np.corrcoef(a[:-1, 0], a[1:, 0])[0, 1]) < 0.03 and abs(np.corrcoef(a[:, 0], a[:, 1])[0, 1]) < 0.03
+    a2 = pol.forward(o1, p1, explore=True, seed=11, counter=5).cpu().numpy()
+    np.testing.assert_array_equal(a2, a.astype(np.float32))                             # same stream -> same draw
+    a3 = pol.forward(o1, p1, explore=True, seed=11, counter=6).cpu().numpy()
+    a4 = pol.forward(o1, p1, explore=True, seed=12, counter=5).cpu().numpy()
+    assert np.mean(a3 == a2) < 0.01 and np.mean(a4 == a2) < 0.01
+
+
+def test_policy_exploring_rollout_is_a_sample_batch(PG, kernel):
+    """qd_rollout_policy with explore: step t draws from stream (seed, counter0 + t); logp / value / logits columns equal
+    what T x (qd_policy_act, qd_step) produce"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    pol = DevicePolicy("RMA_full", weights_of(PG, "rma_full"))
+    cfg = dict(base_config, num_drones=100, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=1024, auto_reset=True)
+    T = 12
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    out = pol.rollout(e1._dev, T, o1, explore=True, seed=99, counter0=40, want_logp=True, want_value=True)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a, lp, v = pol.forward(obs, prev, tr, explore=True, seed=99, counter=40 + t, want_logp=True, want_value=True)
+        np.testing.assert_allclose(out["actions"][t].cpu().numpy(), a.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(out["logp"][t].cpu().numpy(), lp.cpu().numpy(), atol=1e-4)
+        np.testing.assert_allclose(out["value"][t].cpu().numpy(), v.cpu().numpy(), atol=1e-5)
+        ob, rw, trn = e2.vector_step_tensor(a)
+        obs, prev, tr = ob.clone(), a, trn.clone()
+        np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=1e-5)
+    assert float(out["actions"].std()) > 0.05
