@@ -55,17 +55,18 @@ __device__ __forceinline__ float pol_gamma(float a, const PolSample& s, uint32_t
 }
 
 // logits (LDS rows lgt[r * ldl + c]) -> actions / logp / logits in global memory for the workgroup's POL_TILE envs.
-// `scratch` = POL_SCRATCH floats of LDS nobody else uses; every thread of the workgroup must call this (it has a barrier).
+// `scratch` = POL_SCRATCH floats of LDS nobody else uses; every thread of the workgroup must call this (it has a barrier
+// when logp is requested).
 __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, int AD, int env0, int n_envs, int tid, float* scratch,
                                             const PolSample& smp, float* __restrict__ actions, float* __restrict__ logp,
-                                            float* __restrict__ logits) {
+                                            float* __restrict__ logits, float* act_lds = nullptr) {
   if (logits)
     for (int k = tid; k < POL_TILE * NL; k += POL_THREADS) {
       const int r = k / NL, c = k - r * NL;
       if (env0 + r < n_envs) logits[(size_t)(env0 + r) * NL + c] = lgt[r * ldl + c];
     }
   const int H = NL >> 1;
-  if (actions || logp) {
+  if (actions || logp || act_lds) {
     for (int k = tid; k < POL_TILE * H; k += POL_THREADS) {
       const int r = k / H, c = k - r * H;
       const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + c], -50.f, 50.f);
@@ -78,6 +79,7 @@ __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, i
         x = al * __builtin_amdgcn_rcpf(al + be);
       }
       if (actions && env0 + r < n_envs) actions[(size_t)(env0 + r) * AD + c] = x;
+      if (act_lds) act_lds[r * AD + c] = x;  // fused rollouts: the env step of the same workgroup consumes it
       if (logp && H <= POL_SCRATCH / POL_TILE) {
         const float xc = qclamp(x, 0.01f, 0.99f);
         scratch[r * H + c] = (al - 1.0f) * __logf(xc) + (be - 1.0f) * __logf(1.0f - xc) - (pol_lgamma(al) + pol_lgamma(be) - pol_lgamma(al + be));

@@ -40,3 +40,8 @@ for n in (4096, 16384):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     print("closed loop RMA_full n=%d: %.2f us/step, %.3e env-steps/s" % (n, dt / T * 1e6, n * T / dt), flush=True)
+    t0 = time.perf_counter()
+    out = pol.rollout(env._dev, T, o, explore=True, seed=1, want_logp=True, want_value=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("   exploring + logp + value   n=%d: %.2f us/step, %.3e env-steps/s" % (n, dt / T * 1e6, n * T / dt), flush=True)

@@ -194,3 +194,40 @@ def test_policy_exploring_rollout_is_a_sample_batch(PG, kernel):
         obs, prev, tr = ob.clone(), a, trn.clone()
         np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=1e-5)
     assert float(out["actions"].std()) > 0.05
+
+
+def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
+    """k_rollout_fused (one launch per fragment) against the per-step path driven from Python (qd_policy_act + qd_step),
+    deterministic and exploring, with in-kernel auto-resets (truncation every 9 steps) and a ragged env count"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    monkeypatch.delenv("QD_POLICY_GENERIC", raising=False)
+    for tag, fam in TAGS.items():
+        pol = DevicePolicy(fam, weights_of(PG, tag))
+        assert pol.kernel > 0
+        cfg = dict(base_config, num_drones=203, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+                   state_difficulty=0.2, max_steps=9, auto_reset=True)
+        for explore in (False, True):
+            T = 25
+            e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+            o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+            out = pol.rollout(e1._dev, T, o1, explore=explore, seed=5, counter0=7, want_logp=True, want_value=True, want_logits=True)
+            obs, prev, tr = o2, None, None
+            for t in range(T):
+                a, lp, lg, v = pol.forward(obs, prev, tr, explore=explore, seed=5, counter=7 + t, want_logp=True, want_logits=True, want_value=True)
+                np.testing.assert_allclose(out["logits"][t].cpu().numpy(), lg.cpu().numpy(), atol=2e-5, err_msg="%s t=%d" % (tag, t))
+                np.testing.assert_allclose(out["actions"][t].cpu().numpy(), a.cpu().numpy(), atol=2e-5)
+                np.testing.assert_allclose(out["logp"][t].cpu().numpy(), lp.cpu().numpy(), atol=2e-3)
+                np.testing.assert_allclose(out["value"][t].cpu().numpy(), v.cpu().numpy(), atol=2e-5)
+                ob, rw, trn = e2.vector_step_tensor(out["actions"][t])      # same actions into the reference env: no drift
+                obs, prev, tr = ob.clone(), out["actions"][t], trn.clone()
+                np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), atol=2e-5)
+                np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=2e-5)
+                assert torch.equal(out["truncated"][t], tr)
+            assert int(out["truncated"].sum()) == 2 * 203
+            q1 = [x.cpu().numpy() for x in e1._dev.get_state()]
+            q2 = [x.cpu().numpy() for x in e2._dev.get_state()]
+            for x, y in zip(q1, q2):
+                np.testing.assert_allclose(x, y, atol=2e-5)
