@@ -591,6 +591,22 @@ __global__ __launch_bounds__(64) void k_rollout_pid(KArgs a, int T, float* __res
   }
 }
 
+// the env phase of the fused loop as a real call: its ~250 registers (float64 core) are allocated apart from the policy code's
+template <bool LOAD, int SPEC>
+__device__ __attribute__((noinline)) void fused_env_phase(const KArgs& a, int i, const float* action4, float* obs_row, float* reward_out,
+                                                          uint8_t* trunc_out, uint8_t* trunc_lds) {
+  EnvRegs e;
+  load_env<LOAD, false>(a, i, e);
+  const float4 action = *reinterpret_cast<const float4*>(action4);
+  float r;
+  uint8_t tr;
+  env_step<LOAD, SPEC>(a, i, e, action, obs_row, &r, &tr);
+  store_env(a, i, e);
+  *reward_out = r;
+  *trunc_out = tr;
+  *trunc_lds = tr;
+}
+
 // ---- fused closed loop: policy forward + env step for T steps in ONE launch ----
 // A workgroup owns 16 envs for the whole fragment: the four waves run the specialised policy network on the matrix
 // cores (qd_policy_static.h), then lanes 0..15 of wave 0 advance their envs and hand the new observation rows to the
@@ -666,17 +682,8 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
     if (wave == 0) {
       if (envlane) {
         // the env state goes through the arena every step (it stays in this CU's L2 slice): holding it in registers across
-        // the policy phase as k_rollout does would add ~70 live registers to the MFMA code and spill
-        EnvRegs e;
-        load_env<LOAD, false>(a, i, e);
-        const float4 action = *reinterpret_cast<const float4*>(atile + lane * 4);
-        float r;
-        uint8_t tr;
-        env_step<LOAD, SPEC>(a, i, e, action, otile + lane * D, &r, &tr);
-        store_env(a, i, e);
-        reward[(size_t)t * n + i] = r;
-        trunc[(size_t)t * n + i] = tr;
-        trt[lane] = tr;
+        // the policy phase as k_rollout does would add ~70 live registers to the MFMA code
+        fused_env_phase<LOAD, SPEC>(a, i, atile + lane * 4, otile + lane * D, reward + (size_t)t * n + i, trunc + (size_t)t * n + i, trt + lane);
       }
       __builtin_amdgcn_wave_barrier();
       for (int k = lane; k < rows * D; k += 64) obs[((size_t)t * n + env0) * D + k] = otile[k];
