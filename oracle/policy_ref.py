@@ -57,6 +57,35 @@ def simple_mlp(w, obs, prev_actions):
     return _seq(w, "_logits", x, acts), _seq(w, "_value_branch", x, acts)[:, 0]
 
 
+def time_cnn2(w, x, prefix="adaptation_module"):
+    """TimeCNN2.forward (RMA_model.py:155-191): x [N, L, F] -> inMLP per time step -> Conv1d(32,32,5,stride 2) ->
+    Conv1d(32,16,5) (no activation between them) -> flatten (channel-major) -> outMLP"""
+    x = np.asarray(x, np.float64)
+    n, L, _ = x.shape
+    y = _seq(w, prefix + ".inMLP", x.reshape(n * L, -1), ["tanh", "tanh", "tanh"]).reshape(n, L, -1)   # [N, L, 32]
+
+    def conv(y, W, b, stride):
+        W, b = np.asarray(W, np.float64), np.asarray(b, np.float64)          # W [out, in, k]
+        k = W.shape[2]
+        pos = range(0, y.shape[1] - k + 1, stride)
+        return np.stack([np.einsum("nki,oik->no", y[:, p:p + k, :], W) + b for p in pos], axis=1)   # [N, P, out]
+    c1 = conv(y, w[prefix + ".tCNN.0.weight"], w[prefix + ".tCNN.0.bias"], 2)
+    c2 = conv(c1, w[prefix + ".tCNN.1.weight"], w[prefix + ".tCNN.1.bias"], 1)
+    flat = np.transpose(c2, (0, 2, 1)).reshape(n, -1)                       # torch flattens [N, C, P]
+    return _seq(w, prefix + ".outMLP", flat, ["tanh", None])
+
+
+def rma_full_adapt(w, obs_history, action_history, num_states=16):
+    """RMA_model.py:77-110 with train_adaptation=True (train_RMA.py:39-45): obs_history [N, L, D] (zero rows before the
+    episode start), action_history [N, L, 4] (the action BEFORE each observation); z_hat = adaptation_module(history)
+    takes the place of the parameter encoding; returns (logits, value, z_hat)"""
+    oh, ah = np.asarray(obs_history, np.float64), np.asarray(action_history, np.float64)
+    s_a = np.concatenate([oh[:, :, :num_states], ah], axis=-1)
+    z_hat = time_cnn2(w, s_a)
+    feat = _seq(w, "_hidden_layers", np.concatenate([s_a[:, -1], z_hat], axis=-1), ["tanh", "tanh", "bn"])
+    return _seq(w, "_logits", feat, ["tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0], z_hat
+
+
 FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp}
 
 

@@ -150,6 +150,32 @@ def main():
         out[tag + "_keys"] = np.array(list(sd.keys()))
         for k, v in sd.items():
             out[tag + "/" + k] = v.numpy()
+    # RMA_full with the adaptation module in the loop (train_RMA.py:39-45: train_adaptation=True, adapt_seq_len=32):
+    # z_hat = TimeCNN2(32-step history of (state, previous action)) replaces the parameter encoding
+    cca = dict(cc, train_adaptation=True)
+    torch.manual_seed(11)
+    model = RMA_full(obs_space, act_space, 8, {"custom_model_config": cca}, "rma_adapt")
+    _randomise(model, gen)
+    with torch.no_grad():                                         # Conv1d biases start at torch's default; make them visible
+        for m in model.modules():
+            if isinstance(m, nn.Conv1d):
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+    model.eval()
+    nh, L = 24, 32
+    obs_h = torch.randn((nh, L, D), generator=gen) * 1.2
+    act_h = torch.rand((nh, L, 4), generator=gen)
+    obs_h[:8, :20] = 0.0                                          # episodes younger than the window: zero-padded rows
+    act_h[:8, :21] = 0.0
+    with torch.no_grad():
+        logits, _ = model.forward({"obs_history": obs_h, "action_history": act_h, "is_training": False}, [], None)
+        value = model.value_function()
+        z_hat = model.z_hat
+    out["rma_adapt_obs_history"], out["rma_adapt_action_history"] = obs_h.numpy(), act_h.numpy()
+    out["rma_adapt_logits"], out["rma_adapt_value"], out["rma_adapt_z_hat"] = logits.numpy(), value.numpy(), z_hat.numpy()
+    sd = model.state_dict()
+    out["rma_adapt_keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        out["rma_adapt/" + k] = v.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

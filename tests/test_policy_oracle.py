@@ -63,3 +63,13 @@ def test_policy_programs_compile_on_the_host(PG, tag):
     bad = type(ops)(*ops)
     bad[3].in_dim = 5000
     assert L.lib().qd_policy_packed_bytes(C.byref(d), bad) == 0 and "op 3" in L.last_error()
+
+
+def test_adaptation_oracle_vs_reference_model(PG):
+    """RMA_full with train_adaptation=True (TimeCNN2 over the 32-step history), incl. zero-padded young episodes"""
+    from oracle import policy_ref as P
+    w = weights_of(PG, "rma_adapt")
+    logits, value, z_hat = P.rma_full_adapt(w, PG["rma_adapt_obs_history"], PG["rma_adapt_action_history"])
+    np.testing.assert_allclose(z_hat, PG["rma_adapt_z_hat"], atol=3e-6)
+    np.testing.assert_allclose(logits, PG["rma_adapt_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["rma_adapt_value"], atol=3e-6)
