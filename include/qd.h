@@ -202,10 +202,15 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
  *                      weights[w_off], b at weights[b_off] (torch.nn.Linear layout)
  *   QD_POL_AFFINE    : out slice = out slice * weights[w_off + c] + weights[b_off + c]
  *                      (eval-mode BatchNorm1d: scale = gamma / sqrt(var + eps), shift = beta - mean * scale)
+ *   QD_POL_RING_LOAD : buf[out_buf][out_off : + rows*width] = the slots of ring `in_buf` written by the last `rows` steps
+ *                      (of this step's bank), oldest first; the fill values for envs at an episode start
+ *   QD_POL_RING_PUSH : this step's slot of ring `out_buf` = buf[in_buf][in_off : + width]; at an episode start every
+ *                      other slot of the ring is set to the fill values
+ * (ring ops need the step `counter` of qd_policy_act: consecutive calls must pass consecutive counters)
  * Outputs: logits[N, n_logits] (n_logits = 2 * act_dim), value[N] (if the program has a value slot) and
  * actions[N, act_dim] = alpha / (alpha + beta) with (alpha, beta) = softplus(clamp(logits, +-50)) + 1.
  * The caller owns the device buffer the packed weights live in (qd_policy_packed_bytes). */
-enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3 };
+enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3, QD_POL_RING_LOAD = 4, QD_POL_RING_PUSH = 5 };
 enum { QD_ACT_NONE = 0, QD_ACT_TANH = 1, QD_ACT_RELU = 2 };
 enum { QD_POL_VALUE_ONLY = 1 };
 typedef struct qd_policy qd_policy;
@@ -214,17 +219,32 @@ typedef struct qd_policy_op {
   int32_t flags, reserved0;     /* QD_POL_VALUE_ONLY: the op feeds only the value head, skipped when value == NULL */
   int64_t w_off, b_off;         /* float offsets into weights_host */
 } qd_policy_op;
+/* per-env history kept between calls (models with a time window, e.g. RMA_full's adaptation module): a ring of `rows`
+ * slots of `width` floats; period 1 = one slot written per step, period 2 = two interleaved banks, each written every
+ * other step (strided temporal convolutions).  At an episode start every slot holds the `width` values at
+ * weights_host[fill_off] (what the network computes from the zero rows RLlib pads young episodes with). */
+typedef struct qd_policy_ring {
+  int32_t rows, width, period, reserved0;
+  int64_t fill_off;
+} qd_policy_ring;
 typedef struct qd_policy_desc {
   int32_t n_ops, n_bufs;
-  int32_t buf_width[4];
+  int32_t buf_width[8];
   int32_t obs_dim, act_dim;
   int32_t logits_buf, logits_off, n_logits;
   int32_t value_buf, value_off; /* value_buf < 0: no value head */
+  int32_t n_rings;              /* 0 for feed-forward policies */
+  qd_policy_ring ring[4];
 } qd_policy_desc;
 size_t qd_policy_packed_bytes(const qd_policy_desc* desc, const qd_policy_op* ops);
 int qd_policy_create(const qd_policy_desc* desc, const qd_policy_op* ops, const float* weights_host, size_t n_weights,
                      void* packed_device, size_t packed_bytes, qd_policy** out);
 int qd_policy_destroy(qd_policy* policy);
+/* device bytes of the per-env history of `num_envs` envs (0 for feed-forward policies); the caller owns the buffer and
+ * passes it as `state` below.  qd_policy_reset_state fills it with the episode-start values for all envs (mask NULL) or
+ * for those with mask[i] != 0; envs whose prev_truncated flag is set are re-initialised inside qd_policy_act itself. */
+size_t qd_policy_state_bytes(qd_policy* policy, int num_envs);
+int qd_policy_reset_state(qd_policy* policy, void* state, int num_envs, const uint8_t* mask, void* stream);
 /* which kernel serves this policy: 0 = the generic layer-program interpreter, > 0 = a compile-time specialisation for
  * one of the reference's networks at the training scripts' sizes (same results; selected on an exact program match;
  * QD_POLICY_GENERIC=1 in the environment forces 0) */
@@ -239,16 +259,16 @@ int qd_policy_forward(qd_policy* policy, int num_envs, const float* obs, const f
  * logp[N] (nullable) = MyBetaDist.logp(action) = sum over dimensions of log Beta(clamp(a, 0.01, 0.99); alpha, beta) -- the
  * action_logp PPO stores next to the sample.  logits / value nullable as above. */
 int qd_policy_act(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions, const uint8_t* prev_truncated,
-                  int explore, uint64_t seed, uint32_t counter, float* actions, float* logp, float* logits, float* value,
-                  void* stream);
+                  int explore, uint64_t seed, uint32_t counter, void* state, float* actions, float* logp, float* logits,
+                  float* value, void* stream);
 /* T closed-loop steps policy -> vector_step enqueued by one call (2 launches per step, no host round trip): what a rollout
  * worker's sampling loop does (rollout.py:64-85, RLlib's sampler): obs0[N,D] is the observation the first action is computed
  * from, prev_actions0[N,4] (nullable) the action before it; step t uses counter0 + t.  Outputs obs[T,N,D], actions[T,N,4],
  * reward[T,N], truncated[T,N] and, nullable, logp[T,N], logits[T,N,n_logits], value[T,N] -- the columns of a PPO sample
  * batch.  Same results as T x (qd_policy_act, qd_step). */
 int qd_rollout_policy(qd_env* env, qd_policy* policy, int T, const float* obs0, const float* prev_actions0, int explore,
-                      uint64_t seed, uint32_t counter0, float* obs, float* actions, float* reward, uint8_t* truncated,
-                      float* logp, float* logits, float* value, void* stream);
+                      uint64_t seed, uint32_t counter0, void* state, float* obs, float* actions, float* reward,
+                      uint8_t* truncated, float* logp, float* logits, float* value, void* stream);
 
 /* _get_obs() on the current simulator state, obs[N,D] */
 int qd_observe(qd_env* env, float* obs, void* stream);

@@ -56,13 +56,18 @@ class QdPolicyOp(C.Structure):
                 ("flags", C.c_int32), ("reserved0", C.c_int32), ("w_off", C.c_int64), ("b_off", C.c_int64)]
 
 
+class QdPolicyRing(C.Structure):
+    _fields_ = [("rows", C.c_int32), ("width", C.c_int32), ("period", C.c_int32), ("reserved0", C.c_int32),
+                ("fill_off", C.c_int64)]
+
+
 class QdPolicyDesc(C.Structure):
-    _fields_ = [("n_ops", C.c_int32), ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * 4), ("obs_dim", C.c_int32),
+    _fields_ = [("n_ops", C.c_int32), ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * 8), ("obs_dim", C.c_int32),
                 ("act_dim", C.c_int32), ("logits_buf", C.c_int32), ("logits_off", C.c_int32), ("n_logits", C.c_int32),
-                ("value_buf", C.c_int32), ("value_off", C.c_int32)]
+                ("value_buf", C.c_int32), ("value_off", C.c_int32), ("n_rings", C.c_int32), ("ring", QdPolicyRing * 4)]
 
 
-POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV = 0, 1, 2, 3
+POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH = 0, 1, 2, 3, 4, 5
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 POL_VALUE_ONLY = 1
 
@@ -99,8 +104,10 @@ SIGNATURES = {
     "qd_policy_destroy": (_I, [_VP]),
     "qd_policy_kernel": (_I, [_VP]),
     "qd_policy_forward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
-    "qd_policy_act": (_I, [_VP, _I, _VP, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP]),
-    "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_policy_act": (_I, [_VP, _I, _VP, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_policy_state_bytes": (C.c_size_t, [_VP, _I]),
+    "qd_policy_reset_state": (_I, [_VP, _VP, _I, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),
     "qd_drone_states": (_I, [_VP, _VP, _VP]),
     "qd_eval_obs": (_I, [_I, _I, _VP, _D4, _VP, _I, _VP]),

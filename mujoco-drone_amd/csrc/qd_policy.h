@@ -25,17 +25,17 @@
 
 namespace qd {
 
-constexpr int POL_MAX_OPS = 24, POL_MAX_BUFS = 4, POL_WAVES = POL_THREADS / 64;  // POL_TILE, POL_THREADS: qd_policy_dist.h
+constexpr int POL_MAX_OPS = 32, POL_MAX_BUFS = 8, POL_MAX_RINGS = 4, POL_WAVES = POL_THREADS / 64;  // POL_TILE, POL_THREADS: qd_policy_dist.h
 constexpr int POL_KC = 4;       // k-blocks (of 16 inputs) per step
 constexpr int POL_DESC = 16;    // ints per op descriptor
 constexpr int POL_SDESC = 32;   // ints per step descriptor
-enum { POL_DENSE = 0, POL_AFFINE = 1, POL_COPY_OBS = 2, POL_COPY_PREV = 3 };
+enum { POL_DENSE = 0, POL_AFFINE = 1, POL_COPY_OBS = 2, POL_COPY_PREV = 3, POL_RING_LOAD = 4, POL_RING_PUSH = 5 };
 enum { POL_ACT_NONE = 0, POL_ACT_TANH = 1, POL_ACT_RELU = 2 };
 enum { POL_FLAG_VALUE_ONLY = 1 };  // the op only feeds the value head: skipped when no value output is requested
 enum { POL_STEP_FIRST = 1, POL_STEP_LAST = 2, POL_STEP_VALUE_ONLY = 4 };
 
 // op descriptor (POL_DESC ints, written by pol_compile)
-enum { OD_KIND = 0, OD_FLAGS, OD_SRC_OFF, OD_COUNT, OD_OUT, OD_LD_OUT, OD_SCALE, OD_SHIFT };
+enum { OD_KIND = 0, OD_FLAGS, OD_SRC_OFF, OD_COUNT, OD_OUT, OD_LD_OUT, OD_SCALE, OD_SHIFT, OD_RING, OD_IN, OD_LD_IN };
 // step descriptor (POL_SDESC ints): one wave, POL_KC k-blocks of up to four output tiles of one dense op.
 // SD_LANE + u: 1 if tile slot u is used (lanes read consecutive float4s) else 0 (all lanes read one word);
 // SD_OFF + 4 u + d: float4 offset of k-block d of tile slot u in the weight region (0 for unused slots, the last live
@@ -53,6 +53,10 @@ struct PolArgs {
   int logits_lds, ld_logits, n_logits;   // LDS float offset of env row 0's logits, row stride
   int value_lds, ld_value;               // value_lds < 0: the program has no value head
   long long weights_off;      // float offset of the packed weights in the blob
+  // per-env history rings (see qd_policy_ring in include/qd.h)
+  int n_rings, state_floats;                     // floats of history per env
+  int ring_rows[POL_MAX_RINGS], ring_width[POL_MAX_RINGS], ring_period[POL_MAX_RINGS];
+  int ring_off[POL_MAX_RINGS], ring_fill[POL_MAX_RINGS];  // offset in the env's history block; fill values in the small region
 };
 
 typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
@@ -149,11 +153,25 @@ __device__ __forceinline__ void pol_mac(const PolStep& s, const PolBuf& w, const
   }
 }
 
+// qd_policy_reset_state: every ring slot of the selected envs <- the ring's episode-start values (read from the blob)
+__global__ __launch_bounds__(256) void k_policy_reset_state(PolArgs p, float* __restrict__ state, int n_envs, const uint8_t* __restrict__ mask) {
+  const float* small = p.packed + p.prog_ints;
+  const size_t total = (size_t)n_envs * p.state_floats;
+  for (size_t k = (size_t)blockIdx.x * 256 + threadIdx.x; k < total; k += (size_t)gridDim.x * 256) {
+    const int e = (int)(k / p.state_floats), o = (int)(k - (size_t)e * p.state_floats);
+    if (mask && !mask[e]) continue;
+    int rg = 0;
+    while (rg + 1 < p.n_rings && o >= p.ring_off[rg + 1]) rg++;
+    state[k] = small[p.ring_fill[rg] + (o - p.ring_off[rg]) % p.ring_width[rg]];
+  }
+}
+
 __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, const float* __restrict__ obs,
                                                         const float* __restrict__ prev_actions,
                                                         const uint8_t* __restrict__ prev_truncated, PolSample smp,
-                                                        float* __restrict__ actions, float* __restrict__ logp,
-                                                        float* __restrict__ logits, float* __restrict__ value) {
+                                                        float* __restrict__ state, float* __restrict__ actions,
+                                                        float* __restrict__ logp, float* __restrict__ logits,
+                                                        float* __restrict__ value) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -223,6 +241,42 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
       for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
         const int r = k / n, c = k - r * n;
         b[r * ld + c] = fmaf(b[r * ld + c], sc[c], sh[c]);
+      }
+    } else if (kind == POL_RING_LOAD || kind == POL_RING_PUSH) {
+      // history rings: slot written at step t is t mod rows (period 2: bank t & 1, slot (t >> 1) mod rows)
+      const int rg = od[OD_RING];
+      const int R = p.ring_rows[rg], W = p.ring_width[rg], per = p.ring_period[rg];
+      const unsigned tt = per == 2 ? smp.counter >> 1 : smp.counter;
+      const int bank = per == 2 ? (int)(smp.counter & 1u) : 0;
+      const float* fill = small + p.ring_fill[rg];
+      if (kind == POL_RING_LOAD) {
+        float* b = lds + od[OD_OUT];
+        const int ld = od[OD_LD_OUT];
+        for (int k = tid; k < POL_TILE * R * W; k += POL_THREADS) {
+          const int r = k / (R * W), rem = k - r * (R * W), j = rem / W, c = rem - j * W;
+          const int e = env0 + r;
+          float v = 0.f;
+          if (e < n_envs) {
+            const bool fresh = prev_truncated && prev_truncated[e];  // first observation of a new episode
+            const int slot = (int)((tt + (unsigned)j) % (unsigned)R);
+            v = fresh ? fill[c] : state[(size_t)e * p.state_floats + p.ring_off[rg] + (bank * R + slot) * W + c];
+          }
+          b[r * ld + j * W + c] = v;
+        }
+      } else {
+        const float* b = lds + od[OD_IN];
+        const int ld = od[OD_LD_IN];
+        const int slot_new = (int)(tt % (unsigned)R);
+        for (int k = tid; k < POL_TILE * W; k += POL_THREADS) {
+          const int r = k / W, c = k - r * W;
+          const int e = env0 + r;
+          if (e < n_envs) {
+            float* ring = state + (size_t)e * p.state_floats + p.ring_off[rg];
+            if (prev_truncated && prev_truncated[e])
+              for (int q = 0; q < per * R; q++) ring[q * W + c] = fill[c];
+            ring[(bank * R + slot_new) * W + c] = b[r * ld + c];
+          }
+        }
       }
     } else {
       float* b = lds + od[OD_OUT];

@@ -323,6 +323,7 @@ template <class A>
 __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_envs, const float* __restrict__ obs,
                                                                const float* __restrict__ prev_actions,
                                                                const uint8_t* __restrict__ prev_truncated, PolSample smp,
+                                                               float* __restrict__ /*state: feed-forward networks have none*/,
                                                                float* __restrict__ actions, float* __restrict__ logp,
                                                                float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ float lds[];
@@ -383,7 +384,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
 template <class A>
 inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
   const SProg& s = A::prog;
-  if (d->n_ops != s.n_ops || d->n_bufs != s.n_bufs || d->obs_dim != s.obs_dim || d->act_dim != s.act_dim) return false;
+  if (d->n_ops != s.n_ops || d->n_bufs != s.n_bufs || d->n_rings != 0 || d->obs_dim != s.obs_dim || d->act_dim != s.act_dim) return false;
   if (d->logits_buf != s.logits_buf || d->logits_off != s.logits_off || d->n_logits != s.n_logits) return false;
   if (d->value_buf != s.value_buf || d->value_off != s.value_off) return false;
   for (int b = 0; b < s.n_bufs; b++)

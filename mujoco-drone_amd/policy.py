@@ -6,6 +6,9 @@ Families (eval mode; constructor arguments as in train_PPO.py:39-45):
   "RMA_full"        models/PPO/RMA/RMA_model.py:17-110 with train_adaptation=False
   "RMA_model"       models/PPO/RMA/RMA_model.py:199-292
   "SimpleMLPmodel"  models/PPO/SimpleMLP/SimpleMLP.py:18-98
+  "RMA_full_adapt"  RMA_full with train_adaptation=True, adapt_seq_len=32 (train_RMA.py:39-45): the adaptation CNN over the
+                    32-step history, evaluated incrementally from per-env rings (pass consecutive `counter`s; call
+                    reset_state at the start; envs flagged in prev_truncated restart their history by themselves)
 The deterministic action is MyBetaDist's (distributions.py:8-26).  There is no CPU path: everything runs in
 libqd.so's k_policy kernel.
 """
@@ -30,6 +33,7 @@ class _Program:
         self.w = {k: np.asarray(v.detach().cpu().numpy() if hasattr(v, "detach") else v) for k, v in weights.items()}
         self.ops, self.blob, self.n = [], [], 0
         self.flags = 0   # set to POL_VALUE_ONLY while the value head's ops are emitted
+        self.rings = []  # (rows, width, period, fill offset)
 
     def _put(self, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float32).ravel()
@@ -52,6 +56,27 @@ class _Program:
                                      {None: L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU}[act], self.flags, 0,
                                      self._put(W), self._put(b)))
         return out_dim
+
+    def dense(self, W, b, src, dst, act):
+        """explicit weight matrix W [out, in] / bias b"""
+        out_dim, in_dim = W.shape
+        self.ops.append(L.QdPolicyOp(L.POL_DENSE, src[0], src[1], in_dim, dst[0], dst[1], out_dim,
+                                     {None: L.ACT_NONE, "tanh": L.ACT_TANH, "relu": L.ACT_RELU}[act], self.flags, 0,
+                                     self._put(W), self._put(b)))
+        return out_dim
+
+    def ring(self, rows, width, period, fill):
+        """declare a history ring; returns its index"""
+        self.rings.append((int(rows), int(width), int(period), self._put(np.asarray(fill, dtype=np.float32))))
+        return len(self.rings) - 1
+
+    def ring_load(self, ring, dst):
+        rows, width = self.rings[ring][0], self.rings[ring][1]
+        self.ops.append(L.QdPolicyOp(L.POL_RING_LOAD, ring, 0, rows * width, dst[0], dst[1], rows * width, 0, self.flags, 0, 0, 0))
+
+    def ring_push(self, src, ring):
+        width = self.rings[ring][1]
+        self.ops.append(L.QdPolicyOp(L.POL_RING_PUSH, src[0], src[1], width, ring, 0, width, 0, self.flags, 0, 0, 0))
 
     def bn(self, prefix, buf, off):
         """eval-mode BatchNorm1d `prefix` in place"""
@@ -118,7 +143,60 @@ def _simple_mlp(p, D, ns, npar, na):
     return dict(widths=[32, 32, 256, 128], logits=(X, 0, nl), value=(P, 0))
 
 
-_FAMILIES = {"RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp}
+def _f32_fc(W, b, x, tanh):
+    y = (np.asarray(W, np.float32) @ np.asarray(x, np.float32) + np.asarray(b, np.float32)).astype(np.float32)
+    return np.tanh(y).astype(np.float32) if tanh else y
+
+
+def _rma_full_adapt(p, D, ns, npar, na):
+    """RMA_full with train_adaptation=True (RMA_model.py:77-110, TimeCNN2 :155-191; train_RMA.py:39-45, adapt_seq_len 32).
+
+    The reference re-runs the whole adaptation CNN on the 32-step window every step.  Its pieces are functions of fixed
+    absolute time windows -- inMLP acts per time step, Conv1d(32,32,5,stride 2) output p covers rows 2p..2p+4 of the
+    window, Conv1d(32,16,5) output q covers conv1 outputs q..q+4 -- and the window slides by one row per step, so a
+    conv1 / conv2 output computed at step t is the neighbouring output of step t+2.  The program therefore keeps three
+    per-env rings (the last 5 inMLP rows; per step parity the last 4 conv1 and the last 9 conv2 outputs), computes ONE new
+    value of each per step (20->32->32->32, 160->32, 160->16) and reads the rest back: same numbers, 14x / 10x fewer
+    convolution MACs, 2.8 KB of history per env instead of a [32, 20] observation window plus recomputation.  Rows
+    before the episode start are zero in the reference (RLlib's zero padding); their images (inMLP(0) and what the
+    convolutions make of it) are the rings' episode-start fill values."""
+    X, P, A, B, H, C1, C2 = 0, 1, 2, 3, 4, 5, 6
+    w, am = p.w, "adaptation_module."
+    nf = ns + na
+    W1 = np.transpose(w[am + "tCNN.0.weight"], (0, 2, 1)).reshape(32, 5 * 32)     # [out, k*32 + in]: rows of the window
+    W2 = np.transpose(w[am + "tCNN.1.weight"], (0, 2, 1)).reshape(16, 5 * 32)
+    Wo = w[am + "outMLP.0._model.0.weight"]                                         # columns: channel-major flatten [16][10]
+    Wo = np.transpose(Wo.reshape(Wo.shape[0], 16, 10), (0, 2, 1)).reshape(Wo.shape[0], 160)   # -> position-major [10][16]
+    y0 = np.zeros(nf, np.float32)
+    for k in range(3):
+        y0 = _f32_fc(w[am + "inMLP.%d._model.0.weight" % k], w[am + "inMLP.%d._model.0.bias" % k], y0, True)
+    c1z = _f32_fc(W1, w[am + "tCNN.0.bias"], np.tile(y0, 5), False)
+    c2z = _f32_fc(W2, w[am + "tCNN.1.bias"], np.tile(c1z, 5), False)
+    ry, r1, r2 = p.ring(5, 32, 1, y0), p.ring(4, 32, 2, c1z), p.ring(9, 16, 2, c2z)
+    p.copy_obs(0, ns, X, 0); p.copy_prev(na, X, ns)                                 # RMA_model.py:87-89: the newest (state, action) row
+    p.ring_load(ry, (H, 0)); p.ring_load(r1, (C1, 0)); p.ring_load(r2, (C2, 0))
+    p.fc(am + "inMLP.0", (X, 0), (A, 0), "tanh"); p.fc(am + "inMLP.1", (A, 0), (B, 0), "tanh")
+    p.fc(am + "inMLP.2", (B, 0), (P, 0), "tanh")
+    p.dense(W1, w[am + "tCNN.0.bias"], (H, 0), (C1, 4 * 32), None)                  # conv1 over the 5 rows BEFORE the newest one
+    p.ring_push((P, 0), ry)
+    p.dense(W2, w[am + "tCNN.1.bias"], (C1, 0), (C2, 9 * 16), None)
+    p.ring_push((C1, 4 * 32), r1)
+    p.dense(Wo, w[am + "outMLP.0._model.0.bias"], (C2, 0), (A, 0), "tanh")
+    p.ring_push((C2, 9 * 16), r2)
+    z = p.fc(am + "outMLP.1", (A, 0), (X, nf), None)                                # z_hat next to flat_in (:101-105)
+    p.fc("_hidden_layers.0", (X, 0), (A, 0), "tanh")
+    f = p.fc("_hidden_layers.1", (A, 0), (B, 0), "tanh")
+    p.bn("_hidden_layers.2", B, 0)
+    p.fc("_logits.0", (B, 0), (A, 0), "tanh")
+    nl = p.fc("_logits.1", (A, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[max(32, nf + z), 32, 256, max(f, 128), 160, 160, 160], logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 
 
 def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):
@@ -128,8 +206,12 @@ def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, nu
     prog = _Program(weights)
     lay = _FAMILIES[family](prog, int(obs_dim), int(num_states), int(num_params), int(num_actions))
     d = L.QdPolicyDesc()
-    d.n_ops, d.n_bufs = len(prog.ops), 4
-    d.buf_width[:] = [int(x) for x in lay["widths"]]
+    d.n_ops, d.n_bufs = len(prog.ops), len(lay["widths"])
+    for b, x in enumerate(lay["widths"]):
+        d.buf_width[b] = int(x)
+    d.n_rings = len(prog.rings)
+    for r, (rows, width, period, fill_off) in enumerate(prog.rings):
+        d.ring[r].rows, d.ring[r].width, d.ring[r].period, d.ring[r].fill_off = rows, width, period, fill_off
     d.obs_dim, d.act_dim = int(obs_dim), int(num_actions)
     d.logits_buf, d.logits_off, d.n_logits = lay["logits"]
     d.value_buf, d.value_off = lay["value"]
@@ -202,6 +284,8 @@ class DevicePolicy:
                                               nbytes, C.byref(handle)))
         self.handle = handle
         self.kernel = int(self.lib.qd_policy_kernel(handle))   # 0: generic interpreter, > 0: specialised
+        self.has_history = int(d.n_rings) > 0
+        self.state = None                                       # per-env history (models with a time window), see reset_state
         self.n_weights, self.n_ops = int(blob.size), int(d.n_ops)
 
     def __del__(self):
@@ -220,6 +304,26 @@ class DevicePolicy:
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
 
+    def reset_state(self, n, mask=None):
+        """start new episodes: the per-env history of a windowed model (RMA_full_adapt) is set to what the reference's
+        zero-padded window gives; all n envs, or those with mask != 0.  No-op for feed-forward policies."""
+        if not self.has_history:
+            return
+        nbytes = int(self.lib.qd_policy_state_bytes(self.handle, int(n)))
+        if self.state is None or self.state.numel() != nbytes:
+            if mask is not None:
+                raise ValueError("the history must first be initialised for all envs")
+            self.state = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+        m = mask.to(device=self.device, dtype=torch.uint8).contiguous() if mask is not None else None
+        L.check(self.lib.qd_policy_reset_state(self.handle, _ptr(self.state), int(n), _ptr(m), self._stream()))
+
+    def _state_for(self, n):
+        if not self.has_history:
+            return None
+        if self.state is None or self.state.numel() != int(self.lib.qd_policy_state_bytes(self.handle, int(n))):
+            self.reset_state(n)
+        return self.state
+
     def forward(self, obs, prev_actions=None, prev_truncated=None, want_logits=False, want_value=False, out=None,
                 explore=False, seed=0, counter=0, want_logp=False):
         """model.forward + the action RLlib takes from MyBetaDist [+ value_function] for obs [N,D]:
@@ -235,7 +339,8 @@ class DevicePolicy:
         logits = torch.empty((n, self.n_logits), **kw) if want_logits else None
         value = torch.empty((n,), **kw) if want_value else None
         L.check(self.lib.qd_policy_act(self.handle, n, _ptr(obs), _ptr(prev), _ptr(tr), int(bool(explore)), int(seed) & (2 ** 64 - 1),
-                                       int(counter) & 0xFFFFFFFF, _ptr(actions), _ptr(logp), _ptr(logits), _ptr(value), self._stream()))
+                                       int(counter) & 0xFFFFFFFF, _ptr(self._state_for(n)), _ptr(actions), _ptr(logp), _ptr(logits),
+                                       _ptr(value), self._stream()))
         res = (actions,) + ((logp,) if want_logp else ()) + ((logits,) if want_logits else ()) + ((value,) if want_value else ())
         return res[0] if len(res) == 1 else res
 
@@ -256,7 +361,8 @@ class DevicePolicy:
         if want_value:
             out["value"] = torch.empty((T, n), **kw)
         L.check(self.lib.qd_rollout_policy(env.handle, self.handle, T, _ptr(obs0), _ptr(prev), int(bool(explore)),
-                                           int(seed) & (2 ** 64 - 1), int(counter0) & 0xFFFFFFFF, _ptr(out["obs"]), _ptr(out["actions"]),
+                                           int(seed) & (2 ** 64 - 1), int(counter0) & 0xFFFFFFFF, _ptr(self._state_for(n)),
+                                           _ptr(out["obs"]), _ptr(out["actions"]),
                                            _ptr(out["reward"]), _ptr(out["truncated"]), _ptr(out.get("logp")), _ptr(out.get("logits")),
                                            _ptr(out.get("value")), self._stream()))
         return out

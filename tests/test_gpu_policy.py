@@ -231,3 +231,49 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
             q2 = [x.cpu().numpy() for x in e2._dev.get_state()]
             for x, y in zip(q1, q2):
                 np.testing.assert_allclose(x, y, atol=2e-5)
+
+
+def test_adaptation_policy_incremental_history_vs_full_recomputation(PG):
+    """RMA_full with the adaptation CNN (train_RMA.py's configuration): the device evaluates it incrementally from per-env
+    rings, one new inMLP / conv1 / conv2 value per step; the oracle re-runs the whole TimeCNN2 on the explicit 32-step
+    zero-padded window every step, as the reference does.  50 steps, episodes restarting at different times (history
+    re-initialised inside the kernel from the prev_truncated flags), both step parities, ragged batch."""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    rng = np.random.default_rng(12)
+    w = weights_of(PG, "rma_adapt")
+    pol = DevicePolicy("RMA_full_adapt", w)
+    assert pol.kernel == 0 and pol.has_history
+    n, T, Lw, D = 37, 50, 32, 22
+    obs_seq = rng.normal(scale=1.2, size=(T, n, D)).astype(np.float32)
+    act_seq = rng.uniform(0, 1, (T, n, 4)).astype(np.float32)          # the action taken AFTER obs_seq[t] (fed back as previous action)
+    start = np.zeros(n, dtype=np.int64)                                  # first step of each env's current episode
+    restart = {7: np.arange(n) % 3 == 0, 20: np.arange(n) % 2 == 1, 21: np.arange(n) % 5 == 0, 45: np.ones(n, bool)}
+    pol.reset_state(n)
+    worst = 0.0
+    for t in range(T):
+        fresh = restart.get(t, np.zeros(n, bool)) if t > 0 else np.zeros(n, bool)
+        start[fresh] = t
+        prev = np.where((start == t)[:, None], 0.0, act_seq[t - 1] if t > 0 else np.zeros((n, 4))).astype(np.float32)
+        a, logits, value = pol.forward(torch.tensor(obs_seq[t], device="cuda"), torch.tensor(prev, device="cuda"),
+                                       torch.tensor(fresh.astype(np.uint8), device="cuda") if t > 0 else None,
+                                       counter=t, want_logits=True, want_value=True)
+        # the explicit windows the reference's view requirements would hand to the model
+        oh, ah = np.zeros((n, Lw, D)), np.zeros((n, Lw, 4))
+        for j in range(Lw):
+            tau = t - (Lw - 1) + j
+            live = tau >= start
+            if tau >= 0:
+                oh[live, j] = obs_seq[tau][live]
+                if tau >= 1:
+                    inside = live & (tau - 1 >= start)                  # the action before the episode's first obs is zero
+                    ah[inside, j] = act_seq[tau - 1][inside]
+        wl, wv, _ = P.rma_full_adapt(w, oh, ah)
+        worst = max(worst, float(np.abs(logits.cpu().numpy() - wl).max()), float(np.abs(value.cpu().numpy() - wv).max()))
+        np.testing.assert_allclose(logits.cpu().numpy(), wl, atol=3e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(value.cpu().numpy(), wv, atol=3e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(a.cpu().numpy(), P.beta_mean_action(wl), atol=1e-5)
+    print("adaptation policy, incremental vs full recomputation: worst |logit / value error| %.2e" % worst)
+    with pytest.raises(ValueError):
+        pol.lib and __import__("mujoco_drone_amd._lib", fromlist=["check"]).check(
+            pol.lib.qd_policy_forward(pol.handle, n, None, None, None, None, None, None, None))
