@@ -387,6 +387,24 @@ def main():
                     torch.cuda.synchronize()
                     extras["policy_sample_batch_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)  # sampled actions + logp + value
                     extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
+                    # train_RMA.py's network: RMA_full with the adaptation CNN over the 32-step history (incremental, per-env rings)
+                    pad = DevicePolicy("RMA_full_adapt", random_weights("RMA_full_adapt", 4), device=device)
+                    pad.reset_state(n)
+                    for k in range(20):
+                        pad.forward(o3, out=pa, counter=k)
+                    ev0.record()
+                    for k in range(200):
+                        pad.forward(o3, out=pa, counter=20 + k)
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    extras["adapt_policy_forward_us"] = ev0.elapsed_time(ev1) * 1000.0 / 200
+                    pad.reset_state(n)
+                    pad.rollout(e3._dev, 64, o3)
+                    torch.cuda.synchronize()
+                    t1 = time.perf_counter()
+                    pad.rollout(e3._dev, 1024, o3, counter0=64)
+                    torch.cuda.synchronize()
+                    extras["adapt_policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
                 other = "config2" if args.config != "config2" else "config3"
                 e4, alg4 = make_env(other, n, 5, device)
                 (e4.vector_reset_tensor() if other == "config3" else e4.reset())

@@ -633,6 +633,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
   c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
   c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
   c.n_envs = rows; c.env0 = 0; c.want_value = value != nullptr;
+  c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
   SPre<A, J0> pre;
   s_prefetch<A, J0>(c, pre);
   {  // prologue: parameters mirror, first observation / previous action, cleared activations

@@ -17,13 +17,18 @@ namespace qd {
 struct SOp {
   int kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act, flags;
 };
-constexpr int SPROG_MAX = 24;
+constexpr int SPROG_MAX = 32;
+struct SRing {
+  int rows, width, period;
+};
 struct SProg {
   int n_ops;
   SOp op[SPROG_MAX];
   int n_bufs, width[POL_MAX_BUFS];
   int obs_dim, act_dim;
   int logits_buf, logits_off, n_logits, value_buf, value_off;
+  int n_rings;
+  SRing ring[POL_MAX_RINGS];
 };
 
 // ---- layout, the same arithmetic as pol_compile (qd_policy_host.inc) ----
@@ -43,8 +48,19 @@ constexpr long long sp_w_at(const SProg& p, int k) {  // floats, within the weig
     if (p.op[i].kind == POL_DENSE) off += (long long)sp_ntiles(p, i) * sp_k16(p, i) * 256;
   return off;
 }
-constexpr int sp_s_at(const SProg& p, int k) {  // floats, within the small region
+constexpr int sp_ring_fill(const SProg& p, int r) {  // the rings' episode-start values open the small region
   int off = 0;
+  for (int i = 0; i < r; i++) off += (p.ring[i].width + 3) / 4 * 4;
+  return off;
+}
+constexpr int sp_ring_off(const SProg& p, int r) {  // floats, within one env's history block
+  int off = 0;
+  for (int i = 0; i < r; i++) off += p.ring[i].period * p.ring[i].rows * p.ring[i].width;
+  return off;
+}
+constexpr int sp_state_floats(const SProg& p) { return sp_ring_off(p, p.n_rings); }
+constexpr int sp_s_at(const SProg& p, int k) {  // floats, within the small region
+  int off = sp_ring_fill(p, p.n_rings);
   for (int i = 0; i < k; i++) {
     if (p.op[i].kind == POL_DENSE) off += sp_ntiles(p, i) * 16;
     else if (p.op[i].kind == POL_AFFINE) off += (2 * p.op[i].out_dim + 3) / 4 * 4;
@@ -64,17 +80,19 @@ constexpr bool sp_fused_affine(const SProg& p, int k) {
          p.op[k + 1].out_off == p.op[k].out_off && p.op[k + 1].out_dim == p.op[k].out_dim && p.op[k + 1].flags == p.op[k].flags;
 }
 constexpr int sp_small_floats(const SProg& p) {
-  int off = 0;
+  int off = sp_ring_fill(p, p.n_rings);
   for (int i = 0; i < p.n_ops; i++) {
     if (p.op[i].kind == POL_DENSE) off += (p.op[i].out_dim + 15) / 16 * 16;
     else if (p.op[i].kind == POL_AFFINE) off += (2 * p.op[i].out_dim + 3) / 4 * 4;
   }
   return (off + 3) / 4 * 4;
 }
-// leading input gathers (COPY ops before anything else): done in the prologue, under one global-load latency
+// leading input gathers (COPY / RING_LOAD ops before anything else): done in the prologue, under one global-load latency
 constexpr int sp_leading_copies(const SProg& p) {
   int n = 0;
-  while (n < p.n_ops && (p.op[n].kind == POL_COPY_OBS || p.op[n].kind == POL_COPY_PREV) && !(p.op[n].flags & POL_FLAG_VALUE_ONLY)) n++;
+  while (n < p.n_ops && (p.op[n].kind == POL_COPY_OBS || p.op[n].kind == POL_COPY_PREV || p.op[n].kind == POL_RING_LOAD) &&
+         !(p.op[n].flags & POL_FLAG_VALUE_ONLY))
+    n++;
   return n;
 }
 
@@ -112,6 +130,23 @@ struct ArchSimpleMlp {  // models/PPO/SimpleMLP/SimpleMLP.py:18-98
       4, {32, 32, 256, 128}, 22, 4, SX, 0, 8, SP, 0};
 };
 
+constexpr int SH = 4, SC1 = 5, SC2 = 6;
+struct ArchRmaFullAdapt {  // RMA_full with train_adaptation=True, adapt_seq_len 32 (train_RMA.py:39-45); see policy.py:_rma_full_adapt
+  static constexpr SProg prog = {23,
+      {{POL_COPY_OBS, 0, 0, 16, SX, 0, 16, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 16, 4, 0, 0},
+       {POL_RING_LOAD, 0, 0, 160, SH, 0, 160, 0, 0}, {POL_RING_LOAD, 1, 0, 128, SC1, 0, 128, 0, 0}, {POL_RING_LOAD, 2, 0, 144, SC2, 0, 144, 0, 0},
+       {POL_DENSE, SX, 0, 20, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SB, 0, 32, TANH, 0}, {POL_DENSE, SB, 0, 32, SP, 0, 32, TANH, 0},
+       {POL_DENSE, SH, 0, 160, SC1, 128, 32, 0, 0}, {POL_RING_PUSH, SP, 0, 32, 0, 0, 32, 0, 0},
+       {POL_DENSE, SC1, 0, 160, SC2, 144, 16, 0, 0}, {POL_RING_PUSH, SC1, 128, 32, 1, 0, 32, 0, 0},
+       {POL_DENSE, SC2, 0, 160, SA, 0, 64, TANH, 0}, {POL_RING_PUSH, SC2, 144, 16, 2, 0, 16, 0, 0},
+       {POL_DENSE, SA, 0, 64, SX, 20, 8, 0, 0},
+       {POL_DENSE, SX, 0, 28, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_AFFINE, SB, 0, 128, SB, 0, 128, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0}, {POL_DENSE, SA, 0, 128, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      7, {32, 32, 256, 128, 160, 160, 160}, 22, 4, SP, 0, 8, SX, 0,
+      3, {{5, 32, 1}, {4, 32, 2}, {9, 16, 2}}};
+};
+
 // ---- the specialised kernel ----
 struct SCtx {
   float* lds;
@@ -122,6 +157,9 @@ struct SCtx {
   const uint8_t* prev_truncated;
   int n_envs, env0, tid, wave, li, lg;
   bool want_value;
+  const float* small_global;  // the small region in the blob (the prologue reads ring fill values before the LDS mirror exists)
+  float* state;            // per-env history rings (windowed networks)
+  unsigned counter;        // the caller's step counter: selects ring slots and banks
 };
 
 constexpr int SPF = 8;  // k-blocks of the next dense layer requested before the current layer's barrier
@@ -216,13 +254,80 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   }
 }
 
+template <class A, int I> struct SCopy {  // one leading gather: COPY_OBS / COPY_PREV row slice or a RING_LOAD window
+  static constexpr SOp OP = A::prog.op[I < A::prog.n_ops ? I : 0];
+  static constexpr int N = OP.kind == POL_RING_LOAD ? OP.out_dim : OP.in_dim;
+  static constexpr int IT = (POL_TILE * N + POL_THREADS - 1) / POL_THREADS;
+  float v[IT];
+};
+template <class A, int I>
+__device__ __forceinline__ void s_copy_load(const SCtx& c, SCopy<A, I>& r) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int n = SCopy<A, I>::N, obs_dim = A::prog.obs_dim, act_dim = A::prog.act_dim;
+#pragma unroll
+  for (int it = 0; it < SCopy<A, I>::IT; it++) {
+    const int k = c.tid + it * POL_THREADS;
+    const int row = k / n, col = k - row * n, e = c.env0 + row;
+    float v = 0.f;
+    if (k < POL_TILE * n && e < c.n_envs) {
+      if constexpr (op.kind == POL_COPY_OBS) {
+        v = c.obs[(size_t)e * obs_dim + op.in_off + col];
+      } else if constexpr (op.kind == POL_COPY_PREV) {
+        if (c.prev_actions && !(c.prev_truncated && c.prev_truncated[e])) v = c.prev_actions[(size_t)e * act_dim + op.in_off + col];
+      } else {  // POL_RING_LOAD: the slots written by the last R steps of this step's bank, oldest first
+        constexpr int rg = op.in_buf, R = A::prog.ring[rg].rows, W = A::prog.ring[rg].width, per = A::prog.ring[rg].period;
+        constexpr int off = sp_ring_off(A::prog, rg), fill = sp_ring_fill(A::prog, rg), S = sp_state_floats(A::prog);
+        const unsigned tt = per == 2 ? c.counter >> 1 : c.counter;
+        const int bank = per == 2 ? (int)(c.counter & 1u) : 0;
+        const int j = col / W, cc = col - j * W;
+        const int slot = (int)((tt + (unsigned)j) % (unsigned)R);
+        const bool fresh = c.prev_truncated && c.prev_truncated[e];
+        // the fill values are read from the blob here (the LDS mirror is not written yet in the prologue)
+        v = fresh ? c.small_global[fill + cc] : c.state[(size_t)e * S + off + (bank * R + slot) * W + cc];
+      }
+    }
+    r.v[it] = v;
+  }
+}
+template <class A, int I>
+__device__ __forceinline__ void s_copy_store(const SCtx& c, const SCopy<A, I>& r) {
+  constexpr SOp op = A::prog.op[I];
+  constexpr int n = SCopy<A, I>::N, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+#pragma unroll
+  for (int it = 0; it < SCopy<A, I>::IT; it++) {
+    const int k = c.tid + it * POL_THREADS;
+    const int row = k / n, col = k - row * n;
+    if (k < POL_TILE * n) c.lds[out_base + row * ld + col] = r.v[it];
+  }
+}
 template <class A, int I>
 __device__ __forceinline__ void s_other(const SCtx& c) {
   constexpr SOp op = A::prog.op[I];
-  constexpr int ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+  constexpr int OB = op.kind == POL_RING_PUSH ? 0 : op.out_buf;  // a push's out_buf is a ring index, not a buffer
+  constexpr int ld = sp_ld(A::prog, OB), out_base = sp_base(A::prog, OB) + op.out_off;
   constexpr int s_at = sp_s_at(A::prog, I), obs_dim = A::prog.obs_dim, act_dim = A::prog.act_dim;
   float* b = c.lds + out_base;
-  if constexpr (op.kind == POL_AFFINE) {
+  if constexpr (op.kind == POL_RING_PUSH) {
+    constexpr int rg = op.out_buf, R = A::prog.ring[rg].rows, W = A::prog.ring[rg].width, per = A::prog.ring[rg].period;
+    constexpr int off = sp_ring_off(A::prog, rg), fill = sp_ring_fill(A::prog, rg), S = sp_state_floats(A::prog);
+    constexpr int ld_in = sp_ld(A::prog, op.in_buf), in_base = sp_base(A::prog, op.in_buf) + op.in_off;
+    const unsigned tt = per == 2 ? c.counter >> 1 : c.counter;
+    const int bank = per == 2 ? (int)(c.counter & 1u) : 0;
+    const int slot_new = (int)(tt % (unsigned)R);
+    for (int k = c.tid; k < POL_TILE * W; k += POL_THREADS) {
+      const int r = k / W, col = k - r * W, e = c.env0 + r;
+      if (e < c.n_envs) {
+        float* ring = c.state + (size_t)e * S + off;
+        if (c.prev_truncated && c.prev_truncated[e])
+          for (int q = 0; q < per * R; q++) ring[q * W + col] = c.small[fill + col];
+        ring[(bank * R + slot_new) * W + col] = c.lds[in_base + r * ld_in + col];
+      }
+    }
+  } else if constexpr (op.kind == POL_RING_LOAD) {
+    SCopy<A, I> tmp;  // a ring load that is not in the prologue
+    s_copy_load<A, I>(c, tmp);
+    s_copy_store<A, I>(c, tmp);
+  } else if constexpr (op.kind == POL_AFFINE) {
     constexpr int n = op.out_dim;
     const float* sc = c.small + s_at;
     for (int k = c.tid; k < POL_TILE * n; k += POL_THREADS) {
@@ -244,38 +349,6 @@ __device__ __forceinline__ void s_other(const SCtx& c) {
   }
 }
 
-template <class A, int I> struct SCopy {
-  static constexpr int N = A::prog.op[I < A::prog.n_ops ? I : 0].in_dim;
-  static constexpr int IT = (POL_TILE * N + POL_THREADS - 1) / POL_THREADS;
-  float v[IT];
-};
-template <class A, int I>
-__device__ __forceinline__ void s_copy_load(const SCtx& c, SCopy<A, I>& r) {
-  constexpr SOp op = A::prog.op[I];
-  constexpr int n = op.in_dim, obs_dim = A::prog.obs_dim, act_dim = A::prog.act_dim;
-#pragma unroll
-  for (int it = 0; it < SCopy<A, I>::IT; it++) {
-    const int k = c.tid + it * POL_THREADS;
-    const int row = k / n, col = k - row * n, e = c.env0 + row;
-    float v = 0.f;
-    if (k < POL_TILE * n && e < c.n_envs) {
-      if constexpr (op.kind == POL_COPY_OBS) v = c.obs[(size_t)e * obs_dim + op.in_off + col];
-      else if (c.prev_actions && !(c.prev_truncated && c.prev_truncated[e])) v = c.prev_actions[(size_t)e * act_dim + op.in_off + col];
-    }
-    r.v[it] = v;
-  }
-}
-template <class A, int I>
-__device__ __forceinline__ void s_copy_store(const SCtx& c, const SCopy<A, I>& r) {
-  constexpr SOp op = A::prog.op[I];
-  constexpr int n = op.in_dim, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
-#pragma unroll
-  for (int it = 0; it < SCopy<A, I>::IT; it++) {
-    const int k = c.tid + it * POL_THREADS;
-    const int row = k / n, col = k - row * n;
-    if (k < POL_TILE * n) c.lds[out_base + row * ld + col] = r.v[it];
-  }
-}
 // the first LC ops are input gathers: all their loads are issued together (with the small region's) in the prologue
 template <class A, int I, int LC> struct SLead {
   SCopy<A, I> cur;
@@ -323,7 +396,7 @@ template <class A>
 __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_envs, const float* __restrict__ obs,
                                                                const float* __restrict__ prev_actions,
                                                                const uint8_t* __restrict__ prev_truncated, PolSample smp,
-                                                               float* __restrict__ /*state: feed-forward networks have none*/,
+                                                               float* __restrict__ state,
                                                                float* __restrict__ actions, float* __restrict__ logp,
                                                                float* __restrict__ logits, float* __restrict__ value) {
   extern __shared__ float lds[];
@@ -336,6 +409,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
+  c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter;
   // the first dense layer's weights are requested before anything else
   constexpr int J0 = sp_next_dense(A::prog, 0);
   POL_STAMP(0);
@@ -384,7 +458,9 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
 template <class A>
 inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
   const SProg& s = A::prog;
-  if (d->n_ops != s.n_ops || d->n_bufs != s.n_bufs || d->n_rings != 0 || d->obs_dim != s.obs_dim || d->act_dim != s.act_dim) return false;
+  if (d->n_ops != s.n_ops || d->n_bufs != s.n_bufs || d->n_rings != s.n_rings || d->obs_dim != s.obs_dim || d->act_dim != s.act_dim) return false;
+  for (int r = 0; r < s.n_rings; r++)
+    if (d->ring[r].rows != s.ring[r].rows || d->ring[r].width != s.ring[r].width || d->ring[r].period != s.ring[r].period) return false;
   if (d->logits_buf != s.logits_buf || d->logits_off != s.logits_off || d->n_logits != s.n_logits) return false;
   if (d->value_buf != s.value_buf || d->value_off != s.value_off) return false;
   for (int b = 0; b < s.n_bufs; b++)
@@ -395,7 +471,7 @@ inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
     if (a.kind != b.kind || a.in_off != b.in_off || a.in_dim != b.in_dim || a.out_buf != b.out_buf || a.out_off != b.out_off ||
         a.out_dim != b.out_dim || a.act != b.act || a.flags != b.flags)
       return false;
-    if (a.kind == QD_POL_DENSE && a.in_buf != b.in_buf) return false;
+    if ((a.kind == QD_POL_DENSE || a.kind == QD_POL_RING_LOAD || a.kind == QD_POL_RING_PUSH) && a.in_buf != b.in_buf) return false;
   }
   return true;
 }
@@ -405,6 +481,7 @@ inline int pol_arch_of(const qd_policy_desc* d, const qd_policy_op* ops) {
   if (pol_matches<ArchRmaFull>(d, ops)) return 1;
   if (pol_matches<ArchRmaModel>(d, ops)) return 2;
   if (pol_matches<ArchSimpleMlp>(d, ops)) return 3;
+  if (pol_matches<ArchRmaFullAdapt>(d, ops)) return 4;
   return 0;
 }
 

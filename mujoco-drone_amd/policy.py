@@ -236,6 +236,15 @@ def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, p
         w[name + ".running_var"] = rng.uniform(0.25, 1.75, n).astype(np.float32)
 
     h_in = num_states + num_actions + param_embed_dim
+    if family == "RMA_full_adapt":   # RMA_full's layers + the adaptation module (TimeCNN2, adapt_seq_len 32)
+        w = random_weights("RMA_full", seed, num_states, num_params, num_actions, param_embed_dim, num_outputs)
+        am, nf = "adaptation_module.", num_states + num_actions
+        fc(am + "inMLP.0", nf, 32); fc(am + "inMLP.1", 32, 32); fc(am + "inMLP.2", 32, 32)
+        for name, (o, i) in (("tCNN.0", (32, 32)), ("tCNN.1", (16, 32))):
+            w[am + name + ".weight"] = (rng.normal(size=(o, i, 5)) / np.sqrt(5 * i)).astype(np.float32)
+            w[am + name + ".bias"] = (0.1 * rng.normal(size=o)).astype(np.float32)
+        fc(am + "outMLP.0", 160, 64); fc(am + "outMLP.1", 64, param_embed_dim)
+        return w
     if family == "RMA_full":
         fc("param_encoder.0", num_params, 32); fc("param_encoder.1", 32, param_embed_dim)
         fc("_hidden_layers.0", h_in, 256); fc("_hidden_layers.1", 256, 128); bn("_hidden_layers.2", 128)

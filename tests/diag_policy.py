@@ -25,6 +25,20 @@ for tag, fam in (("rma_full", "RMA_full"), ("rma_model", "RMA_model"), ("simple_
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1000 / 200
         print("%-14s n=%6d forward %.2f us  (%.1f GFLOP/s incl. value head)" % (fam, n, us, 0), flush=True)
+wa = {k: PG["rma_adapt/" + k] for k in PG["rma_adapt_keys"]}
+pa = DevicePolicy("RMA_full_adapt", wa)
+for n in (4096, 16384):
+    obs = torch.randn((n, 22), device="cuda"); prev = torch.rand((n, 4), device="cuda"); out = torch.empty((n, 4), device="cuda")
+    pa.reset_state(n)
+    for k in range(20):
+        pa.forward(obs, prev, out=out, counter=k)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for k in range(200):
+        pa.forward(obs, prev, out=out, counter=20 + k)
+    e1.record(); torch.cuda.synchronize()
+    print("RMA_full_adapt n=%6d forward %.2f us (kernel %d)" % (n, e0.elapsed_time(e1) * 1000 / 200, pa.kernel), flush=True)
 w = {k: PG["rma_full/" + k] for k in PG["rma_full_keys"]}
 pol = DevicePolicy("RMA_full", w)
 for n in (4096, 16384):

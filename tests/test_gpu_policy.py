@@ -233,7 +233,7 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
                 np.testing.assert_allclose(x, y, atol=2e-5)
 
 
-def test_adaptation_policy_incremental_history_vs_full_recomputation(PG):
+def test_adaptation_policy_incremental_history_vs_full_recomputation(PG, kernel):
     """RMA_full with the adaptation CNN (train_RMA.py's configuration): the device evaluates it incrementally from per-env
     rings, one new inMLP / conv1 / conv2 value per step; the oracle re-runs the whole TimeCNN2 on the explicit 32-step
     zero-padded window every step, as the reference does.  50 steps, episodes restarting at different times (history
@@ -243,7 +243,7 @@ def test_adaptation_policy_incremental_history_vs_full_recomputation(PG):
     rng = np.random.default_rng(12)
     w = weights_of(PG, "rma_adapt")
     pol = DevicePolicy("RMA_full_adapt", w)
-    assert pol.kernel == 0 and pol.has_history
+    assert (pol.kernel > 0) == (kernel == "specialised") and pol.has_history
     n, T, Lw, D = 37, 50, 32, 22
     obs_seq = rng.normal(scale=1.2, size=(T, n, D)).astype(np.float32)
     act_seq = rng.uniform(0, 1, (T, n, 4)).astype(np.float32)          # the action taken AFTER obs_seq[t] (fed back as previous action)
@@ -277,3 +277,31 @@ def test_adaptation_policy_incremental_history_vs_full_recomputation(PG):
     with pytest.raises(ValueError):
         pol.lib and __import__("mujoco_drone_amd._lib", fromlist=["check"]).check(
             pol.lib.qd_policy_forward(pol.handle, n, None, None, None, None, None, None, None))
+
+
+def test_adaptation_policy_rollout(PG, kernel):
+    """closed loop with the windowed policy: qd_rollout_policy carries the history through the fragment (and restarts it
+    for envs the step kernel re-sampled) exactly as T x (qd_policy_act, qd_step) does"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    w = weights_of(PG, "rma_adapt")
+    p1, p2 = DevicePolicy("RMA_full_adapt", w), DevicePolicy("RMA_full_adapt", w)
+    cfg = dict(base_config, num_drones=150, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=11, auto_reset=True)
+    T = 40
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    p1.reset_state(150); p2.reset_state(150)
+    out = p1.rollout(e1._dev, T, o1, counter0=3, want_logits=True, want_value=True)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a, lg, v = p2.forward(obs, prev, tr, counter=3 + t, want_logits=True, want_value=True)
+        np.testing.assert_allclose(out["logits"][t].cpu().numpy(), lg.cpu().numpy(), atol=1e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(out["value"][t].cpu().numpy(), v.cpu().numpy(), atol=1e-5)
+        ob, rw, trn = e2.vector_step_tensor(out["actions"][t])
+        obs, prev, tr = ob.clone(), out["actions"][t], trn.clone()
+        assert torch.equal(out["truncated"][t], tr)
+    assert int(out["truncated"].sum()) == 3 * 150
+    np.testing.assert_array_equal(p1.state.cpu().numpy(), p2.state.cpu().numpy())
