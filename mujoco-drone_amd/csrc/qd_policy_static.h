@@ -147,6 +147,28 @@ struct ArchRmaFullAdapt {  // RMA_full with train_adaptation=True, adapt_seq_len
       3, {{5, 32, 1}, {4, 32, 2}, {9, 16, 2}}};
 };
 
+struct ArchCnnEst {  // CNNestimator, use_estimate=False (StateEstimatorLSTM.py:200-283; train_LSTM.py:51-60): 23-value observation
+  static constexpr SProg prog = {9,
+      {{POL_COPY_OBS, 0, 0, 19, SX, 0, 19, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 19, 4, 0, 0}, {POL_COPY_OBS, 0, 19, 4, SX, 23, 4, 0, 0},
+       {POL_DENSE, SX, 0, 27, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      4, {32, 16, 256, 128}, 23, 4, SP, 0, 8, SX, 0, 0, {}};
+};
+struct ArchCnnEstHist {  // CNNestimator, use_estimate=True: TimeCNN over the 32-step history, incremental (policy.py:_cnn_estimator_estimate)
+  static constexpr SProg prog = {20,
+      {{POL_COPY_OBS, 0, 0, 19, SX, 0, 19, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 19, 4, 0, 0},
+       {POL_RING_LOAD, 0, 0, 160, SH, 0, 160, 0, 0}, {POL_RING_LOAD, 1, 0, 128, SC1, 0, 128, 0, 0}, {POL_RING_LOAD, 2, 0, 144, SC2, 0, 144, 0, 0},
+       {POL_DENSE, SX, 0, 23, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SP, 0, 32, TANH, 0},
+       {POL_DENSE, SH, 0, 160, SC1, 128, 32, 0, 0}, {POL_RING_PUSH, SP, 0, 32, 0, 0, 32, 0, 0},
+       {POL_DENSE, SC1, 0, 160, SC2, 144, 16, 0, 0}, {POL_RING_PUSH, SC1, 128, 32, 1, 0, 32, 0, 0},
+       {POL_DENSE, SC2, 0, 160, SA, 0, 32, TANH, 0}, {POL_RING_PUSH, SC2, 144, 16, 2, 0, 16, 0, 0},
+       {POL_DENSE, SA, 0, 32, SX, 23, 4, 0, 0},
+       {POL_DENSE, SX, 0, 27, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      7, {32, 32, 256, 128, 160, 160, 160}, 23, 4, SP, 0, 8, SX, 0,
+      3, {{5, 32, 1}, {4, 32, 2}, {9, 16, 2}}};
+};
+
 // ---- the specialised kernel ----
 struct SCtx {
   float* lds;
@@ -482,6 +504,8 @@ inline int pol_arch_of(const qd_policy_desc* d, const qd_policy_op* ops) {
   if (pol_matches<ArchRmaModel>(d, ops)) return 2;
   if (pol_matches<ArchSimpleMlp>(d, ops)) return 3;
   if (pol_matches<ArchRmaFullAdapt>(d, ops)) return 4;
+  if (pol_matches<ArchCnnEst>(d, ops)) return 5;
+  if (pol_matches<ArchCnnEstHist>(d, ops)) return 6;
   return 0;
 }
 

@@ -6,6 +6,8 @@ Families (eval mode; constructor arguments as in train_PPO.py:39-45):
   "RMA_full"        models/PPO/RMA/RMA_model.py:17-110 with train_adaptation=False
   "RMA_model"       models/PPO/RMA/RMA_model.py:199-292
   "SimpleMLPmodel"  models/PPO/SimpleMLP/SimpleMLP.py:18-98
+  "CNNestimator"    models/PPO/CustomLSTM/StateEstimatorLSTM.py:200-283 with use_estimate=False (train_LSTM.py:51-60; obs_dim =
+                    num_states = 23); "CNNestimator_estimate": use_estimate=True, TimeCNN over the 32-step history, incremental
   "RMA_full_adapt"  RMA_full with train_adaptation=True, adapt_seq_len=32 (train_RMA.py:39-45): the adaptation CNN over the
                     32-step history, evaluated incrementally from per-env rings (pass consecutive `counter`s; call
                     reset_state at the start; envs flagged in prev_truncated restart their history by themselves)
@@ -196,7 +198,58 @@ def _rma_full_adapt(p, D, ns, npar, na):
     return dict(widths=[max(32, nf + z), 32, 256, max(f, 128), 160, 160, 160], logits=(P, 0, nl), value=(X, 0))
 
 
-_FAMILIES = {"RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
+def _cnn_estimator(p, D, ns, npar, na):
+    """CNNestimator, use_estimate=False (StateEstimatorLSTM.py:250-283; train_LSTM.py:51-60): ns = num_states = obs_dim = 23"""
+    X, P, A, B = 0, 1, 2, 3
+    p.copy_obs(0, ns - 4, X, 0); p.copy_prev(na, X, ns - 4); p.copy_obs(ns - 4, 4, X, ns - 4 + na)   # cat(flat_in, gt_pendulum_state)
+    p.fc("_hidden.0", (X, 0), (A, 0), "tanh")
+    p.fc("_hidden.1", (A, 0), (B, 0), "tanh")
+    nl = p.fc("_logits.0", (B, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[32, 16, 256, 128], logits=(P, 0, nl), value=(X, 0))
+
+
+def _cnn_estimator_estimate(p, D, ns, npar, na):
+    """CNNestimator, use_estimate=True: the last four observation entries (pendulum state) are replaced by the TimeCNN
+    estimate from the 32-step (obs[:19], previous action) history -- evaluated incrementally like _rma_full_adapt"""
+    X, P, A, B, H, C1, C2 = 0, 1, 2, 3, 4, 5, 6
+    w, em = p.w, "estimation_module."
+    nf = ns - 4 + na
+    W1 = np.transpose(w[em + "tCNN.0.weight"], (0, 2, 1)).reshape(32, 5 * 32)
+    W2 = np.transpose(w[em + "tCNN.1.weight"], (0, 2, 1)).reshape(16, 5 * 32)
+    Wo = w[em + "outMLP.0._model.0.weight"]
+    Wo = np.transpose(Wo.reshape(Wo.shape[0], 16, 10), (0, 2, 1)).reshape(Wo.shape[0], 160)
+    y0 = np.zeros(nf, np.float32)
+    for k in range(2):
+        y0 = _f32_fc(w[em + "inMLP.%d._model.0.weight" % k], w[em + "inMLP.%d._model.0.bias" % k], y0, True)
+    c1z = _f32_fc(W1, w[em + "tCNN.0.bias"], np.tile(y0, 5), False)
+    c2z = _f32_fc(W2, w[em + "tCNN.1.bias"], np.tile(c1z, 5), False)
+    ry, r1, r2 = p.ring(5, 32, 1, y0), p.ring(4, 32, 2, c1z), p.ring(9, 16, 2, c2z)
+    p.copy_obs(0, ns - 4, X, 0); p.copy_prev(na, X, ns - 4)
+    p.ring_load(ry, (H, 0)); p.ring_load(r1, (C1, 0)); p.ring_load(r2, (C2, 0))
+    p.fc(em + "inMLP.0", (X, 0), (A, 0), "tanh")
+    p.fc(em + "inMLP.1", (A, 0), (P, 0), "tanh")
+    p.dense(W1, w[em + "tCNN.0.bias"], (H, 0), (C1, 4 * 32), None)
+    p.ring_push((P, 0), ry)
+    p.dense(W2, w[em + "tCNN.1.bias"], (C1, 0), (C2, 9 * 16), None)
+    p.ring_push((C1, 4 * 32), r1)
+    p.dense(Wo, w[em + "outMLP.0._model.0.bias"], (C2, 0), (A, 0), "tanh")
+    p.ring_push((C2, 9 * 16), r2)
+    p.fc(em + "outMLP.1", (A, 0), (X, nf), None)                                     # the estimate next to flat_in
+    p.fc("_hidden.0", (X, 0), (A, 0), "tanh")
+    p.fc("_hidden.1", (A, 0), (B, 0), "tanh")
+    nl = p.fc("_logits.0", (B, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[32, 32, 256, 128, 160, 160, 160], logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 
 
 def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):
@@ -236,6 +289,18 @@ def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, p
         w[name + ".running_var"] = rng.uniform(0.25, 1.75, n).astype(np.float32)
 
     h_in = num_states + num_actions + param_embed_dim
+    if family in ("CNNestimator", "CNNestimator_estimate"):   # num_states = 23 (LocalFrameFullStateEnv)
+        ns = 23
+        fc("_hidden.0", ns + num_actions, 256); fc("_hidden.1", 256, 128); fc("_logits.0", 128, num_outputs)
+        fc("_value_branch.0", 128, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+        if family == "CNNestimator_estimate":
+            em = "estimation_module."
+            fc(em + "inMLP.0", ns, 32); fc(em + "inMLP.1", 32, 32)
+            for name, (o, i) in (("tCNN.0", (32, 32)), ("tCNN.1", (16, 32))):
+                w[em + name + ".weight"] = (rng.normal(size=(o, i, 5)) / np.sqrt(5 * i)).astype(np.float32)
+                w[em + name + ".bias"] = (0.1 * rng.normal(size=o)).astype(np.float32)
+            fc(em + "outMLP.0", 160, 32); fc(em + "outMLP.1", 32, 4)
+        return w
     if family == "RMA_full_adapt":   # RMA_full's layers + the adaptation module (TimeCNN2, adapt_seq_len 32)
         w = random_weights("RMA_full", seed, num_states, num_params, num_actions, param_embed_dim, num_outputs)
         am, nf = "adaptation_module.", num_states + num_actions

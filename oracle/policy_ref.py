@@ -57,12 +57,13 @@ def simple_mlp(w, obs, prev_actions):
     return _seq(w, "_logits", x, acts), _seq(w, "_value_branch", x, acts)[:, 0]
 
 
-def time_cnn2(w, x, prefix="adaptation_module"):
-    """TimeCNN2.forward (RMA_model.py:155-191): x [N, L, F] -> inMLP per time step -> Conv1d(32,32,5,stride 2) ->
-    Conv1d(32,16,5) (no activation between them) -> flatten (channel-major) -> outMLP"""
+def time_cnn2(w, x, prefix="adaptation_module", in_layers=3):
+    """TimeCNN2.forward (RMA_model.py:155-191; in_layers=3) / TimeCNN.forward (StateEstimatorLSTM.py:312-336; in_layers=2):
+    x [N, L, F] -> inMLP per time step -> Conv1d(32,32,5,stride 2) -> Conv1d(32,16,5) (no activation between them) ->
+    flatten (channel-major) -> outMLP"""
     x = np.asarray(x, np.float64)
     n, L, _ = x.shape
-    y = _seq(w, prefix + ".inMLP", x.reshape(n * L, -1), ["tanh", "tanh", "tanh"]).reshape(n, L, -1)   # [N, L, 32]
+    y = _seq(w, prefix + ".inMLP", x.reshape(n * L, -1), ["tanh"] * in_layers).reshape(n, L, -1)   # [N, L, 32]
 
     def conv(y, W, b, stride):
         W, b = np.asarray(W, np.float64), np.asarray(b, np.float64)          # W [out, in, k]
@@ -84,6 +85,25 @@ def rma_full_adapt(w, obs_history, action_history, num_states=16):
     z_hat = time_cnn2(w, s_a)
     feat = _seq(w, "_hidden_layers", np.concatenate([s_a[:, -1], z_hat], axis=-1), ["tanh", "tanh", "bn"])
     return _seq(w, "_logits", feat, ["tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0], z_hat
+
+
+def cnn_estimator(w, obs, prev_actions, num_states=23):
+    """CNNestimator.forward with use_estimate=False, train_estimator=False (StateEstimatorLSTM.py:250-283; the train_LSTM.py:51-60
+    configuration): hidden(cat(obs[:, :num_states-4], prev_actions, obs[:, num_states-4:])); returns (logits, value)"""
+    obs, prev = np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)
+    x = np.concatenate([obs[:, :num_states - 4], prev, obs[:, num_states - 4:num_states]], axis=-1)
+    feat = _seq(w, "_hidden", x, ["tanh", "tanh"])
+    return _seq(w, "_logits", feat, [None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]
+
+
+def cnn_estimator_hist(w, obs_history, action_history, num_states=23):
+    """the same with use_estimate=True: the pendulum state is replaced by TimeCNN(32-step history of (obs[:19], previous
+    action)); returns (logits, value, estimate)"""
+    oh, ah = np.asarray(obs_history, np.float64), np.asarray(action_history, np.float64)
+    o_a = np.concatenate([oh[:, :, :num_states - 4], ah], axis=-1)
+    est = time_cnn2(w, o_a, "estimation_module", in_layers=2)
+    feat = _seq(w, "_hidden", np.concatenate([o_a[:, -1], est], axis=-1), ["tanh", "tanh"])
+    return _seq(w, "_logits", feat, [None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0], est
 
 
 FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp}

@@ -93,6 +93,8 @@ def _install_ray_standins():
     mod("ray.rllib.utils.typing", Dict=typing.Dict, TensorType=typing.Any, List=typing.List, ModelConfigDict=dict)
     mod("ray.rllib.policy"); mod("ray.rllib.policy.sample_batch", SampleBatch=SampleBatch)
     mod("ray.rllib.policy.view_requirement", ViewRequirement=ViewRequirement)
+    mod("ray.rllib.models.torch.recurrent_net", RecurrentNetwork=type("RecurrentNetwork", (TorchModelV2,), {}))   # only subclassed
+    mod("ray.rllib.policy.rnn_sequencing", add_time_dimension=None)                                              # unused on this path
 
 
 def _randomise(model, gen):
@@ -176,6 +178,43 @@ def main():
     out["rma_adapt_keys"] = np.array(list(sd.keys()))
     for k, v in sd.items():
         out["rma_adapt/" + k] = v.numpy()
+    # train_LSTM.py's network (BASELINE config 5): CNNestimator with use_estimate=False, train_estimator=False -- feed-forward
+    # on the 23-value LocalFrameFullStateEnv observation; and with use_estimate=True: the pendulum state is replaced by the
+    # TimeCNN estimate from the 32-step history
+    from models.PPO.CustomLSTM.StateEstimatorLSTM import CNNestimator
+    D5 = 23
+    obs_space5 = gymnasium.spaces.Box(low=-np.inf, high=np.inf, shape=(D5,))
+    obs5 = torch.randn((n, D5), generator=gen) * 1.3
+    out["obs23"] = obs5.numpy()
+    for tag, use_est in (("cnn_est_ff", False), ("cnn_est_hist", True)):
+        torch.manual_seed(13)
+        model = CNNestimator(obs_space5, act_space, 8, {"custom_model_config": {'num_states': 23, 'num_actions': 4, 'use_estimate': use_est,
+                                                                               'train_estimator': False}, "max_seq_len": 32}, tag)
+        _randomise(model, gen)
+        with torch.no_grad():
+            for m in model.modules():
+                if isinstance(m, nn.Conv1d):
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.1)
+        model.eval()
+        if use_est:
+            oh = torch.randn((nh, L, D5), generator=gen) * 1.2
+            ah = torch.rand((nh, L, 4), generator=gen)
+            oh[:8, :20] = 0.0
+            ah[:8, :21] = 0.0
+            inp = {"obs_history": oh, "action_history": ah, "is_training": False}
+            out[tag + "_obs_history"], out[tag + "_action_history"] = oh.numpy(), ah.numpy()
+        else:
+            inp = {"obs_history": obs5, "action_history": prev, "is_training": False}
+        with torch.no_grad():
+            logits, _ = model.forward(inp, [], None)
+            value = model.value_function()
+        out[tag + "_logits"], out[tag + "_value"] = logits.numpy(), value.numpy()
+        if use_est:
+            out[tag + "_estimate"] = model.pendulum_state_estimate.numpy()
+        sd = {k: v for k, v in model.state_dict().items() if use_est or not k.startswith("estimation_module")}
+        out[tag + "_keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out[tag + "/" + k] = v.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

@@ -233,7 +233,12 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
                 np.testing.assert_allclose(x, y, atol=2e-5)
 
 
-def test_adaptation_policy_incremental_history_vs_full_recomputation(PG, kernel):
+HIST = {"RMA_full_adapt": ("rma_adapt", 22, lambda P, w, oh, ah: P.rma_full_adapt(w, oh, ah)[:2]),
+        "CNNestimator_estimate": ("cnn_est_hist", 23, lambda P, w, oh, ah: P.cnn_estimator_hist(w, oh, ah)[:2])}
+
+
+@pytest.mark.parametrize("family", list(HIST))
+def test_adaptation_policy_incremental_history_vs_full_recomputation(PG, kernel, family):
     """RMA_full with the adaptation CNN (train_RMA.py's configuration): the device evaluates it incrementally from per-env
     rings, one new inMLP / conv1 / conv2 value per step; the oracle re-runs the whole TimeCNN2 on the explicit 32-step
     zero-padded window every step, as the reference does.  50 steps, episodes restarting at different times (history
@@ -241,10 +246,11 @@ def test_adaptation_policy_incremental_history_vs_full_recomputation(PG, kernel)
     from mujoco_drone_amd.policy import DevicePolicy
     from oracle import policy_ref as P
     rng = np.random.default_rng(12)
-    w = weights_of(PG, "rma_adapt")
-    pol = DevicePolicy("RMA_full_adapt", w)
+    tag, D, full = HIST[family]
+    w = weights_of(PG, tag)
+    pol = DevicePolicy(family, w, obs_dim=D, num_states=23 if D == 23 else 16)
     assert (pol.kernel > 0) == (kernel == "specialised") and pol.has_history
-    n, T, Lw, D = 37, 50, 32, 22
+    n, T, Lw = 37, 50, 32
     obs_seq = rng.normal(scale=1.2, size=(T, n, D)).astype(np.float32)
     act_seq = rng.uniform(0, 1, (T, n, 4)).astype(np.float32)          # the action taken AFTER obs_seq[t] (fed back as previous action)
     start = np.zeros(n, dtype=np.int64)                                  # first step of each env's current episode
@@ -268,12 +274,12 @@ def test_adaptation_policy_incremental_history_vs_full_recomputation(PG, kernel)
                 if tau >= 1:
                     inside = live & (tau - 1 >= start)                  # the action before the episode's first obs is zero
                     ah[inside, j] = act_seq[tau - 1][inside]
-        wl, wv, _ = P.rma_full_adapt(w, oh, ah)
+        wl, wv = full(P, w, oh, ah)
         worst = max(worst, float(np.abs(logits.cpu().numpy() - wl).max()), float(np.abs(value.cpu().numpy() - wv).max()))
         np.testing.assert_allclose(logits.cpu().numpy(), wl, atol=3e-5, err_msg="t=%d" % t)
         np.testing.assert_allclose(value.cpu().numpy(), wv, atol=3e-5, err_msg="t=%d" % t)
         np.testing.assert_allclose(a.cpu().numpy(), P.beta_mean_action(wl), atol=1e-5)
-    print("adaptation policy, incremental vs full recomputation: worst |logit / value error| %.2e" % worst)
+    print("%s, incremental vs full recomputation: worst |logit / value error| %.2e" % (family, worst))
     with pytest.raises(ValueError):
         pol.lib and __import__("mujoco_drone_amd._lib", fromlist=["check"]).check(
             pol.lib.qd_policy_forward(pol.handle, n, None, None, None, None, None, None, None))
@@ -305,3 +311,35 @@ def test_adaptation_policy_rollout(PG, kernel):
         assert torch.equal(out["truncated"][t], tr)
     assert int(out["truncated"].sum()) == 3 * 150
     np.testing.assert_array_equal(p1.state.cpu().numpy(), p2.state.cpu().numpy())
+
+
+def test_cnn_estimator_forward_and_fused_config5_rollout(PG, kernel):
+    """train_LSTM.py's network (CNNestimator, feed-forward mode) against the reference model's outputs, and closed-loop on the
+    BASELINE config-5 env (LocalFrameFullStateEnv, pendulum-energy reward, circling waypoint): the fused one-launch rollout
+    equals the per-step loop"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameFullStateEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward_pendulum_en4
+    pol = DevicePolicy("CNNestimator", weights_of(PG, "cnn_est_ff"), obs_dim=23, num_states=23)
+    assert (pol.kernel > 0) == (kernel == "specialised")
+    act, logits, value = pol.forward(torch.tensor(PG["obs23"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda"),
+                                     want_logits=True, want_value=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), PG["cnn_est_ff_logits"], atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), PG["cnn_est_ff_value"], atol=2e-5)
+    cfg = dict(base_config, num_drones=120, reward_fcn=distance_energy_reward_pendulum_en4, random_params=False, state_difficulty=0.8,
+               max_steps=13, auto_reset=True, reference_trajectory=dict(type="circle", radius=1.0, frequency=0.5))
+    T = 30
+    e1, e2 = LocalFrameFullStateEnv(cfg), LocalFrameFullStateEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    out = pol.rollout(e1._dev, T, o1, want_logits=True)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a, lg = pol.forward(obs, prev, tr, want_logits=True)
+        np.testing.assert_allclose(out["logits"][t].cpu().numpy(), lg.cpu().numpy(), atol=2e-5, err_msg="t=%d" % t)
+        ob, rw, trn = e2.vector_step_tensor(out["actions"][t])
+        obs, prev, tr = ob.clone(), out["actions"][t], trn.clone()
+        np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), atol=2e-5)
+        np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=5e-5)
+        assert torch.equal(out["truncated"][t], tr)
+    assert int(out["truncated"].sum()) >= 2 * 120

@@ -73,3 +73,15 @@ def test_adaptation_oracle_vs_reference_model(PG):
     np.testing.assert_allclose(z_hat, PG["rma_adapt_z_hat"], atol=3e-6)
     np.testing.assert_allclose(logits, PG["rma_adapt_logits"], atol=3e-6)
     np.testing.assert_allclose(value, PG["rma_adapt_value"], atol=3e-6)
+
+
+def test_cnn_estimator_oracle_vs_reference_model(PG):
+    """train_LSTM.py's network (CNNestimator), feed-forward and with the TimeCNN estimate in the loop"""
+    from oracle import policy_ref as P
+    logits, value = P.cnn_estimator(weights_of(PG, "cnn_est_ff"), PG["obs23"], PG["prev_actions"])
+    np.testing.assert_allclose(logits, PG["cnn_est_ff_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["cnn_est_ff_value"], atol=3e-6)
+    logits, value, est = P.cnn_estimator_hist(weights_of(PG, "cnn_est_hist"), PG["cnn_est_hist_obs_history"], PG["cnn_est_hist_action_history"])
+    np.testing.assert_allclose(est, PG["cnn_est_hist_estimate"], atol=3e-6)
+    np.testing.assert_allclose(logits, PG["cnn_est_hist_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["cnn_est_hist_value"], atol=3e-6)
