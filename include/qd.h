@@ -235,6 +235,9 @@ typedef struct qd_policy_desc {
   int32_t value_buf, value_off; /* value_buf < 0: no value head */
   int32_t n_rings;              /* 0 for feed-forward policies */
   qd_policy_ring ring[4];
+  int32_t aux_buf, aux_off, aux_dim; /* an intermediate slice callers may read back (qd_policy_aux), e.g. the parameter
+                                        embedding z of the RMA networks (policy.model.z, rollout.py:83); aux_dim 0 = none */
+  int32_t reserved1;
 } qd_policy_desc;
 size_t qd_policy_packed_bytes(const qd_policy_desc* desc, const qd_policy_op* ops);
 int qd_policy_create(const qd_policy_desc* desc, const qd_policy_op* ops, const float* weights_host, size_t n_weights,
@@ -253,6 +256,10 @@ int qd_policy_kernel(qd_policy* policy);
  * NULL; prev_actions / prev_truncated may be NULL (= zeros / no episode boundary) */
 int qd_policy_forward(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions,
                       const uint8_t* prev_truncated, float* actions, float* logits, float* value, void* stream);
+/* one forward pass, returning only the program's auxiliary slice: aux[N, aux_dim] (policy.model.z after compute_actions,
+ * rollout.py:72,83).  Feed-forward policies only (a windowed policy's history would advance). */
+int qd_policy_aux(qd_policy* policy, int num_envs, const float* obs, const float* prev_actions, const uint8_t* prev_truncated,
+                  float* aux, void* stream);
 /* the same forward pass with the action taken as RLlib takes it from MyBetaDist (distributions.py:6-38):
  * explore == 0: deterministic_sample (the Beta mean); explore != 0: a Beta(alpha, beta) draw (TorchBeta.sample; Philox4x32-10
  * stream keyed by `seed`, one stream per (env, counter, action dimension): pass the step number as `counter`);

@@ -64,7 +64,8 @@ class QdPolicyRing(C.Structure):
 class QdPolicyDesc(C.Structure):
     _fields_ = [("n_ops", C.c_int32), ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * 8), ("obs_dim", C.c_int32),
                 ("act_dim", C.c_int32), ("logits_buf", C.c_int32), ("logits_off", C.c_int32), ("n_logits", C.c_int32),
-                ("value_buf", C.c_int32), ("value_off", C.c_int32), ("n_rings", C.c_int32), ("ring", QdPolicyRing * 4)]
+                ("value_buf", C.c_int32), ("value_off", C.c_int32), ("n_rings", C.c_int32), ("ring", QdPolicyRing * 4),
+                ("aux_buf", C.c_int32), ("aux_off", C.c_int32), ("aux_dim", C.c_int32), ("reserved1", C.c_int32)]
 
 
 POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH = 0, 1, 2, 3, 4, 5
@@ -106,6 +107,7 @@ SIGNATURES = {
     "qd_policy_forward": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_policy_act": (_I, [_VP, _I, _VP, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP]),
     "qd_rollout_policy": (_I, [_VP, _VP, _I, _VP, _VP, _I, C.c_uint64, C.c_uint32, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP, _VP]),
+    "qd_policy_aux": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP]),
     "qd_policy_state_bytes": (C.c_size_t, [_VP, _I]),
     "qd_policy_reset_state": (_I, [_VP, _VP, _I, _VP, _VP]),
     "qd_observe": (_I, [_VP, _VP, _VP]),

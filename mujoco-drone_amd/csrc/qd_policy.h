@@ -52,6 +52,7 @@ struct PolArgs {
   int obs_dim, act_dim;
   int logits_lds, ld_logits, n_logits;   // LDS float offset of env row 0's logits, row stride
   int value_lds, ld_value;               // value_lds < 0: the program has no value head
+  int aux_lds, ld_aux, n_aux;            // auxiliary slice read back by qd_policy_aux (n_aux 0: none)
   long long weights_off;      // float offset of the packed weights in the blob
   // per-env history rings (see qd_policy_ring in include/qd.h)
   int n_rings, state_floats;                     // floats of history per env
@@ -171,7 +172,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
                                                         const uint8_t* __restrict__ prev_truncated, PolSample smp,
                                                         float* __restrict__ state, float* __restrict__ actions,
                                                         float* __restrict__ logp, float* __restrict__ logits,
-                                                        float* __restrict__ value) {
+                                                        float* __restrict__ value, float* __restrict__ aux) {
   extern __shared__ float lds[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lg = lane >> 4;
@@ -297,6 +298,11 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
   }
   // outputs: value, then logits / action / log-prob (MyBetaDist, qd_policy_dist.h)
   if (want_value && p.value_lds >= 0 && tid < POL_TILE && env0 + tid < n_envs) value[env0 + tid] = lds[p.value_lds + tid * p.ld_value];
+  if (aux)
+    for (int k = tid; k < POL_TILE * p.n_aux; k += POL_THREADS) {
+      const int r = k / p.n_aux, c = k - r * p.n_aux;
+      if (env0 + r < n_envs) aux[(size_t)(env0 + r) * p.n_aux + c] = lds[p.aux_lds + r * p.ld_aux + c];
+    }
   pol_outputs(lds + p.logits_lds, p.ld_logits, p.n_logits, p.act_dim, env0, n_envs, tid, lds + p.act_floats - POL_SCRATCH, smp, actions, logp, logits);
   POL_STAMP(2 + p.n_ops);
 }

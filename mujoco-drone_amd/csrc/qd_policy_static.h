@@ -29,6 +29,7 @@ struct SProg {
   int logits_buf, logits_off, n_logits, value_buf, value_off;
   int n_rings;
   SRing ring[POL_MAX_RINGS];
+  int aux_buf, aux_off, aux_dim;  // auxiliary slice (the RMA networks' embedding z); aux_dim 0: none
 };
 
 // ---- layout, the same arithmetic as pol_compile (qd_policy_host.inc) ----
@@ -105,7 +106,7 @@ struct ArchRmaFull {  // models/PPO/RMA/RMA_model.py:17-110, train_adaptation=Fa
        {POL_DENSE, SX, 0, 28, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_AFFINE, SB, 0, 128, SB, 0, 128, 0, 0},
        {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0}, {POL_DENSE, SA, 0, 128, SP, 0, 8, 0, 0},
        {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
-      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0};
+      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0, 0, {}, SX, 20, 8};
 };
 struct ArchRmaModel {  // models/PPO/RMA/RMA_model.py:199-292
   static constexpr SProg prog = {16,
@@ -115,7 +116,7 @@ struct ArchRmaModel {  // models/PPO/RMA/RMA_model.py:199-292
        {POL_DENSE, SA, 0, 128, SB, 0, 96, TANH, 0}, {POL_AFFINE, SB, 0, 96, SB, 0, 96, 0, 0},
        {POL_DENSE, SB, 0, 96, SA, 0, 64, TANH, 0}, {POL_DENSE, SA, 0, 64, SA, 64, 64, TANH, 0}, {POL_DENSE, SA, 64, 64, SP, 0, 8, 0, 0},
        {POL_DENSE, SB, 0, 96, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
-      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0};
+      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0, 0, {}, SX, 20, 8};
 };
 struct ArchSimpleMlp {  // models/PPO/SimpleMLP/SimpleMLP.py:18-98
   static constexpr SProg prog = {22,
@@ -168,6 +169,7 @@ struct ArchCnnEstHist {  // CNNestimator, use_estimate=True: TimeCNN over the 32
       7, {32, 32, 256, 128, 160, 160, 160}, 23, 4, SP, 0, 8, SX, 0,
       3, {{5, 32, 1}, {4, 32, 2}, {9, 16, 2}}};
 };
+// (the windowed networks and SimpleMLPmodel / CNNestimator declare no auxiliary slice)
 
 // ---- the specialised kernel ----
 struct SCtx {
@@ -420,7 +422,8 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
                                                                const uint8_t* __restrict__ prev_truncated, PolSample smp,
                                                                float* __restrict__ state,
                                                                float* __restrict__ actions, float* __restrict__ logp,
-                                                               float* __restrict__ logits, float* __restrict__ value) {
+                                                               float* __restrict__ logits, float* __restrict__ value,
+                                                               float* __restrict__ aux) {
   extern __shared__ float lds[];
   constexpr int ACT = sp_act_floats(A::prog);
   SCtx c;
@@ -472,6 +475,14 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   constexpr int v_base = sp_base(A::prog, VB) + A::prog.value_off, v_ld = sp_ld(A::prog, VB);
   constexpr bool has_value = A::prog.value_buf >= 0;
   if (has_value && c.want_value && c.tid < POL_TILE && c.env0 + c.tid < n_envs) value[c.env0 + c.tid] = lds[v_base + c.tid * v_ld];
+  if constexpr (A::prog.aux_dim > 0) {
+    constexpr int NA = A::prog.aux_dim, a_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, a_ld = sp_ld(A::prog, A::prog.aux_buf);
+    if (aux)
+      for (int k = c.tid; k < POL_TILE * NA; k += POL_THREADS) {
+        const int r = k / NA, col = k - r * NA;
+        if (c.env0 + r < n_envs) aux[(size_t)(c.env0 + r) * NA + col] = lds[a_base + r * a_ld + col];
+      }
+  }
   pol_outputs(lds + lg_base, ldl, NL, AD, c.env0, n_envs, c.tid, lds + ACT - POL_SCRATCH, smp, actions, logp, logits);
   POL_STAMP(2 + A::prog.n_ops);
 }
@@ -485,6 +496,7 @@ inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
     if (d->ring[r].rows != s.ring[r].rows || d->ring[r].width != s.ring[r].width || d->ring[r].period != s.ring[r].period) return false;
   if (d->logits_buf != s.logits_buf || d->logits_off != s.logits_off || d->n_logits != s.n_logits) return false;
   if (d->value_buf != s.value_buf || d->value_off != s.value_off) return false;
+  if (d->aux_dim != s.aux_dim || (s.aux_dim > 0 && (d->aux_buf != s.aux_buf || d->aux_off != s.aux_off))) return false;
   for (int b = 0; b < s.n_bufs; b++)
     if ((d->buf_width[b] + 15) / 16 != (s.width[b] + 15) / 16) return false;
   for (int k = 0; k < s.n_ops; k++) {

@@ -103,7 +103,8 @@ def _rma_full(p, D, ns, npar, na):
     m = p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
     p.fc("_value_branch.1", (A, 0), (A, 128 if m <= 128 else 256), "tanh")
     p.fc("_value_branch.2", (A, 128 if m <= 128 else 256), (X, 0), None)
-    return dict(widths=[max(32, ns + na + z), 16, 512 if m > 128 else 256, max(f, 128)], logits=(P, 0, nl), value=(X, 0))
+    return dict(widths=[max(32, ns + na + z), 16, 512 if m > 128 else 256, max(f, 128)], logits=(P, 0, nl), value=(X, 0),
+                aux=(X, ns + na, z))   # self.z, the parameter embedding (RMA_model.py:107)
 
 
 def _rma_model(p, D, ns, npar, na):
@@ -123,7 +124,7 @@ def _rma_model(p, D, ns, npar, na):
     p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
     p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
     p.fc("_value_branch.2", (A, 128), (X, 0), None)
-    return dict(widths=[max(32, ns + na + z), 16, 256, 128], logits=(P, 0, nl), value=(X, 0))
+    return dict(widths=[max(32, ns + na + z), 16, 256, 128], logits=(P, 0, nl), value=(X, 0), aux=(X, ns + na, z))   # self.z (:286)
 
 
 def _simple_mlp(p, D, ns, npar, na):
@@ -268,6 +269,8 @@ def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, nu
     d.obs_dim, d.act_dim = int(obs_dim), int(num_actions)
     d.logits_buf, d.logits_off, d.n_logits = lay["logits"]
     d.value_buf, d.value_off = lay["value"]
+    if "aux" in lay:
+        d.aux_buf, d.aux_off, d.aux_dim = lay["aux"]
     ops = (L.QdPolicyOp * len(prog.ops))(*prog.ops)
     return d, ops, np.concatenate(prog.blob).astype(np.float32)
 
@@ -348,6 +351,7 @@ class DevicePolicy:
         self.family, self.obs_dim, self.act_dim = family, int(obs_dim), int(num_actions)
         d, ops, blob = compile_program(family, weights, obs_dim, num_states, num_params, num_actions)
         self.n_logits = int(d.n_logits)
+        self.aux_dim = int(d.aux_dim)
         nbytes = self.lib.qd_policy_packed_bytes(C.byref(d), ops)
         if nbytes == 0:
             raise ValueError("invalid policy program: " + L.last_error())
@@ -377,6 +381,15 @@ class DevicePolicy:
         if tuple(t.shape) != tuple(shape):
             raise ValueError("expected shape %s, got %s" % (tuple(shape), tuple(t.shape)))
         return t
+
+    def embedding(self, obs, prev_actions=None):
+        """policy.model.z after a forward pass on obs [N,D] (rollout.py:83): the RMA networks' parameter embedding, [N, 8]"""
+        n = int(obs.shape[0])
+        obs = self._f32(obs, (n, self.obs_dim))
+        prev = self._f32(prev_actions, (n, self.act_dim)) if prev_actions is not None else None
+        out = torch.empty((n, self.aux_dim), dtype=torch.float32, device=self.device)
+        L.check(self.lib.qd_policy_aux(self.handle, n, _ptr(obs), _ptr(prev), None, _ptr(out), self._stream()))
+        return out
 
     def reset_state(self, n, mask=None):
         """start new episodes: the per-env history of a windowed model (RMA_full_adapt) is set to what the reference's

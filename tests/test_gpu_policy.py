@@ -343,3 +343,33 @@ def test_cnn_estimator_forward_and_fused_config5_rollout(PG, kernel):
         np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=5e-5)
         assert torch.equal(out["truncated"][t], tr)
     assert int(out["truncated"].sum()) >= 2 * 120
+
+
+def test_dataset_collection_like_rollout_py(PG, tmp_path):
+    """rollout.py:64-86 on the GPU: batches {'z','o','a','t'}; z = policy.model.z = param_encoder(env parameters) against the
+    oracle; parameters are regenerated per batch; pickle round trip"""
+    import pickle
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.rollout import collect_dataset, write_dataset
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    from oracle import policy_ref as P
+    w = weights_of(PG, "rma_full")
+    pol = DevicePolicy("RMA_full", w)
+    env = LocalFrameRPYParamsEnv(dict(base_config, num_drones=64, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+                                      state_difficulty=0.3, max_steps=4096, max_distance=3, auto_reset=True))
+    env.vector_reset_tensor()
+    batches = collect_dataset(env, pol, num_batches=3, rollout_length=6, explore=True, seed=4)
+    assert len(batches) == 3
+    for b in batches:
+        assert b["z"].shape == (64, 8) and b["o"].shape == (6, 64, 22) and b["a"].shape == (6, 64, 4) and b["t"].shape == (6, 64)
+        want = P._seq(w, "param_encoder", b["o"][-1][:, -6:].astype(np.float64), ["tanh", None])   # the env's parameters -> z
+        np.testing.assert_allclose(b["z"], want, atol=1e-5)
+        assert b["a"].min() > 0 and b["a"].max() < 1 and b["t"].dtype == bool
+    assert np.abs(batches[0]["z"] - batches[1]["z"]).max() > 1e-3      # regen: new parameters, new embedding
+    write_dataset(str(tmp_path / "dataset.pickle"), batches)
+    back = pickle.load(open(tmp_path / "dataset.pickle", "rb"))
+    np.testing.assert_array_equal(back[2]["o"], batches[2]["o"])
+    nested = collect_dataset(env, pol, 1, 4, as_lists=True)
+    assert isinstance(nested[0]["o"], list) and len(nested[0]["o"]) == 4 and nested[0]["o"][0].shape == (64, 22)
