@@ -385,6 +385,24 @@ template <class A, int LC> struct SLead<A, LC, LC> {
   __device__ __forceinline__ void store(const SCtx&) const {}
 };
 
+// LDS is not cleared as a whole: every slice a dense layer reads is written earlier in the same launch, except the padding
+// columns that round its K up to whole k-blocks of 16 (and slices a program deliberately reads before writing them, which
+// lie in the same range).  Only those columns are zeroed: they meet zero weights, but must not hold NaNs.
+template <class A, int I>
+__device__ __forceinline__ void s_zero_pads(const SCtx& c) {
+  if constexpr (I < A::prog.n_ops) {
+    constexpr SOp op = A::prog.op[I];
+    if constexpr (op.kind == POL_DENSE) {
+      constexpr int pad0 = op.in_off + op.in_dim, pad1 = op.in_off + sp_k16(A::prog, I) * 16, n = pad1 - pad0;
+      if constexpr (n > 0) {
+        constexpr int ld = sp_ld(A::prog, op.in_buf), base = sp_base(A::prog, op.in_buf) + pad0;
+        for (int k = c.tid; k < POL_TILE * n; k += POL_THREADS) c.lds[base + (k / n) * ld + (k % n)] = 0.f;
+      }
+    }
+    s_zero_pads<A, I + 1>(c);
+  }
+}
+
 // ops I.. of the program; `pre` holds the prefetched weights of dense op J = the first dense op at or after I
 template <class A, int I, int J>
 __device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   }
   SLead<A, 0, LC> lead;
   lead.load(c);
-  for (int k = c.tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;  // padding columns must hold zeros, not NaNs
+  s_zero_pads<A, 0>(c);
   __syncthreads();
   {
     float4* dst = reinterpret_cast<float4*>(lds + ACT);
