@@ -373,3 +373,34 @@ def test_dataset_collection_like_rollout_py(PG, tmp_path):
     np.testing.assert_array_equal(back[2]["o"], batches[2]["o"])
     nested = collect_dataset(env, pol, 1, 4, as_lists=True)
     assert isinstance(nested[0]["o"], list) and len(nested[0]["o"]) == 4 and nested[0]["o"][0].shape == (64, 22)
+
+
+def test_beta_head_at_extreme_logits(PG, kernel):
+    """MyBetaDist at the edges of its clamp (logits from -60 to +60 -> alpha, beta in [1, 51]): mean action, log-prob of the mean
+    and of samples against the float64 oracle (lgamma by Stirling on the device)"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    w = dict(weights_of(PG, "rma_full"))
+    vals = np.array([-60.0, -50.0, -5.0, 0.0, 5.0, 20.0, 50.0, 60.0], np.float32)
+    rng = np.random.default_rng(0)
+    n = 512
+    want_logits = vals[rng.integers(0, len(vals), size=(n, 8))]
+    # the last actor layer outputs its bias only; one network per row would be wasteful, so rows share 8 bias patterns
+    patterns = want_logits[:8]
+    for k in range(8):
+        w["_logits.1._model.0.weight"] = np.zeros_like(w["_logits.1._model.0.weight"])
+        w["_logits.1._model.0.bias"] = patterns[k].copy()
+        pol = DevicePolicy("RMA_full", w)
+        obs = torch.tensor(PG["obs"][:16], device="cuda")
+        a, lp, lg = pol.forward(obs, want_logp=True, want_logits=True)
+        lg64 = lg.cpu().numpy().astype(np.float64)
+        np.testing.assert_allclose(lg64, np.tile(patterns[k], (16, 1)), atol=1e-6)
+        np.testing.assert_allclose(a.cpu().numpy(), P.beta_mean_action(lg64), rtol=2e-6, atol=1e-7)
+        np.testing.assert_allclose(lp.cpu().numpy(), P.beta_logp(lg64, a.cpu().numpy().astype(np.float64)), rtol=2e-5, atol=3e-4)
+        o2 = obs.repeat(64, 1).contiguous()
+        s, lps = pol.forward(o2, explore=True, seed=k, counter=1, want_logp=True)
+        s64 = s.cpu().numpy().astype(np.float64)
+        assert np.all(np.isfinite(s64)) and s64.min() >= 0.0 and s64.max() <= 1.0
+        np.testing.assert_allclose(lps.cpu().numpy(), P.beta_logp(np.tile(patterns[k], (len(s64), 1)).astype(np.float64), s64), rtol=3e-5, atol=1e-3)
+        al, be = P.beta_params(patterns[k].astype(np.float64))
+        np.testing.assert_allclose(s64.mean(0), al / (al + be), atol=0.03)
