@@ -404,3 +404,41 @@ def test_beta_head_at_extreme_logits(PG, kernel):
         np.testing.assert_allclose(lps.cpu().numpy(), P.beta_logp(np.tile(patterns[k], (len(s64), 1)).astype(np.float64), s64), rtol=3e-5, atol=1e-3)
         al, be = P.beta_params(patterns[k].astype(np.float64))
         np.testing.assert_allclose(s64.mean(0), al / (al + be), atol=0.03)
+
+
+def test_policy_api_error_paths(PG):
+    """the C ABI refuses misuse with a status and a message instead of launching"""
+    import ctypes as C
+    from mujoco_drone_amd import _lib as L
+    from mujoco_drone_amd.policy import DevicePolicy, compile_program
+    lib = L.lib()
+    w = weights_of(PG, "rma_full")
+    pol = DevicePolicy("RMA_full", w)
+    obs = torch.zeros((8, 22), device="cuda")
+    out = torch.zeros((8, 4), device="cuda")
+    P = lambda t: C.c_void_p(t.data_ptr())
+    assert lib.qd_policy_forward(pol.handle, 8, P(obs), None, None, None, None, None, None) != 0 and "no output" in L.last_error()
+    assert lib.qd_policy_forward(pol.handle, 0, P(obs), None, None, P(out), None, None, None) != 0
+    assert lib.qd_policy_forward(None, 8, P(obs), None, None, P(out), None, None, None) != 0 and "null policy" in L.last_error()
+    assert lib.qd_policy_act(pol.handle, 8, None, None, None, 0, 0, 0, None, P(out), None, None, None, None) != 0
+    # packed buffer too small / misaligned
+    d, ops, blob = compile_program("RMA_full", w)
+    nbytes = lib.qd_policy_packed_bytes(C.byref(d), ops)
+    small = torch.empty(nbytes - 16, dtype=torch.uint8, device="cuda")
+    h = C.c_void_p()
+    assert lib.qd_policy_create(C.byref(d), ops, blob.ctypes.data_as(C.c_void_p), blob.size, P(small), nbytes - 16, C.byref(h)) == L.QD_ERR_ARENA
+    # a windowed policy needs its state buffer and the step counter
+    wa = weights_of(PG, "rma_adapt")
+    pa = DevicePolicy("RMA_full_adapt", wa)
+    assert lib.qd_policy_forward(pa.handle, 8, P(obs), None, None, P(out), None, None, None) != 0 and "qd_policy_act" in L.last_error()
+    assert lib.qd_policy_act(pa.handle, 8, P(obs), None, None, 0, 0, 0, None, P(out), None, None, None, None) != 0 and "state" in L.last_error()
+    aux = torch.zeros((8, 8), device="cuda")
+    assert lib.qd_policy_aux(pa.handle, 8, P(obs), None, None, P(aux), None) == L.QD_ERR_UNSUPPORTED
+    assert lib.qd_policy_state_bytes(pol.handle, 100) == 0 and lib.qd_policy_state_bytes(pa.handle, 100) == 100 * 704 * 4
+    # obs width mismatch between env and policy in a rollout
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameFullStateEnv
+    env = LocalFrameFullStateEnv(dict(base_config, num_drones=16))
+    o = env.vector_reset_tensor()
+    with pytest.raises(ValueError):
+        pol.rollout(env._dev, 2, o)
