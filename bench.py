@@ -246,7 +246,15 @@ def main():
     # shader clock up (measured: the same K steps are 2-12 % slower after 512 untimed steps than after 8192).  These extra
     # untimed steps come before the W warmup steps of the contract and are reported in config.clock_ramp_steps.
     ramp = max(0, 8192 - W)
-    run(ramp)
+    ramp_s = float(os.environ.get("QD_BENCH_RAMP_S", "0"))
+    if ramp_s > 0:
+        t_r = time.perf_counter()
+        while time.perf_counter() - t_r < ramp_s:
+            run(8192, base=ramp)
+            ramp += 8192
+            torch.cuda.synchronize()
+    else:
+        run(ramp)
     run(W, base=ramp)
     fence()
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
