@@ -197,24 +197,24 @@ def main():
     actions = lo + (hi - lo) * torch.rand((P, n, 4), generator=g, device=device, dtype=torch.float32)
 
     T = min(args.fragment, K)
-    frags = gathers = None
+    # Rollout fragments [T,N,...] the step kernel writes in place; the synthetic actions live in the fragment's action
+    # tensor itself -- where a policy would write them.  Every step is one k_step launch (qd_step); the T launches of a
+    # fragment are enqueued as ONE HIP graph (qd_step_fragment: captured on first use, replayed afterwards), because at
+    # 4096 envs the per-launch host path (4-5.5 us depending on the host CPU) is what bounds a step-by-step loop, not the
+    # 4.1 us kernel.  Steps that do not fill a fragment go through the per-step call.  The envs never exchange data, so
+    # the timed region has no collective; with N > 1 the per-fragment RCCL all-gather that hands trajectories
+    # to a central learner is measured right after it, alone and overlapped with stepping, and reported separately.
     pending = [None, None]
-    if world > 1:
-        # Rollout fragments [T,N,...] the step kernel writes in place; the synthetic actions live in the fragment's
-        # action tensor itself -- where a policy would write them.  The envs never exchange data, so the timed region
-        # has no collective; the per-fragment RCCL all-gather that hands trajectories to a central learner
-        # is measured right after it, alone and overlapped with stepping, and reported separately.
-        frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
-        gathers = [par.FragmentGather(f, world) for f in frags]
-        for f in frags:
-            f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
-    state = {"cur": 0, "gathers": 0}
+    use_graph = args.config != "config2" and not os.environ.get("QD_BENCH_NO_GRAPH")
+    frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
+    gathers = [par.FragmentGather(f, world) for f in frags] if world > 1 else None
+    for f in frags:
+        f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
+    state = {"cur": 0, "gathers": 0, "graph_steps": 0, "call_steps": 0}
 
     def run(k_steps, base=0, gather=False):
-        for t in range(k_steps):
-            if frags is None:
-                step(actions[(base + t) % P])
-                continue
+        t = 0
+        while t < k_steps:
             tt = (base + t) % T
             cur = state["cur"]
             if gather and tt == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
@@ -222,7 +222,15 @@ def main():
                     w.wait()
                 pending[cur] = None
             f = frags[cur]
-            step(f.actions[tt], out=(f.obs[tt], f.rewards[tt], f.truncated[tt]))
+            if use_graph and tt == 0 and k_steps - t >= T:
+                env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
+                state["graph_steps"] += T
+                t += T
+                tt = T - 1
+            else:
+                step(f.actions[tt], out=(f.obs[tt], f.rewards[tt], f.truncated[tt]))
+                state["call_steps"] += 1
+                t += 1
             if tt == T - 1:
                 if gather:
                     pending[cur] = gathers[cur](f, async_op=True)[1]
@@ -257,6 +265,7 @@ def main():
         run(ramp)
     run(W, base=ramp)
     fence()
+    state["graph_steps"] = state["call_steps"] = 0
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
     ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
@@ -264,6 +273,7 @@ def main():
     ev1.record()
     fence()
     dt = time.perf_counter() - t0
+    timed_graph_steps, timed_call_steps = state["graph_steps"], state["call_steps"]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -304,10 +314,11 @@ def main():
         out = {"metric": "env_steps_per_sec", "value": value, "unit": "env steps/s", "n_gpus": world, "steps": K,
                "warmup": W, "ms_per_step": dt / K * 1e3, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "config": {"workload": WORKLOADS[args.config] + ("; trajectories written in place into [T=%d,N,...] fragments (their RCCL all-gather is reported separately in config.trajectory_all_gather)" % T
-                                                                 if world > 1 else ""),
+               "config": {"workload": WORKLOADS[args.config] + "; trajectories written in place into [T=%d,N,...] fragments" % T +
+                                      (" (their RCCL all-gather is reported separately in config.trajectory_all_gather)" if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": "one HIP kernel launch per step through qd_step (C ABI)",
+                          "launch": ("one k_step kernel launch per step (C ABI); %d of the %d timed steps enqueued as HIP graphs of %d launches "
+                                     "(qd_step_fragment), %d through per-step qd_step calls" % (timed_graph_steps, K, T, timed_call_steps)),
                           "precision": "float32 state / trigonometry / drag / integration, float64 inertia assembly and solves (load model)", "parallelism": "env-sharded x%d" % world,
                           "trajectory_all_gather": gather_info}}
         # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
@@ -338,6 +349,13 @@ def main():
         if not args.no_extras and world == 1:
             extras = {}
             try:
+                # the same K steps through the per-step Python API (vector_step_tensor): bound by the host launch path
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for t in range(K):
+                    step(actions[t % P])
+                torch.cuda.synchronize()
+                extras["per_step_api_env_steps_per_s"] = n * K / (time.perf_counter() - t1)
                 sweep = []
                 for nn in (4096, 65536, 1048576, 4194304):
                     e2, alg2 = make_env(args.config, nn, 7, device)

@@ -166,6 +166,12 @@ int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* senso
  * launch and their obs row is the first observation of the new episode. */
 int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
             uint8_t* truncated, void* stream);
+/* T consecutive qd_step launches (same kernels, same results: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N])
+ * enqueued as ONE HIP graph: the first call with a given (T, buffers) captures the launches, later calls replay them, so
+ * the per-step host launch path (~4-5 us, the bound of qd_step at 4096 envs) is paid once per fragment.  For rollout
+ * fragments whose actions are already on the device (replays, or a policy that wrote the whole fragment).  The graph is
+ * captured on a stream owned by the env and replayed in `stream`; qd_set_reference invalidates it. */
+int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
 /* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
  * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated,

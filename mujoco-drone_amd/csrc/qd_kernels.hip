@@ -955,6 +955,21 @@ struct qd_env {
   int D, ns;
   int spec;
   bool load;
+  // qd_step_fragment: the T per-step launches of one fragment, captured once in a HIP graph and replayed; a few graphs are
+  // kept (double-buffered fragments alternate between two sets of buffers)
+  struct Frag {
+    hipGraphExec_t exec = nullptr;
+    const float* actions = nullptr;
+    float* obs = nullptr;
+    float* reward = nullptr;
+    uint8_t* trunc = nullptr;
+    int T = 0;
+    unsigned long long used = 0;
+  };
+  static constexpr int FRAGS = 4;
+  Frag frag[FRAGS];
+  unsigned long long frag_clock = 0;
+  hipStream_t frag_stream = nullptr;
 };
 
 static thread_local char g_err[512] = "";
@@ -1130,6 +1145,11 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
 }
 
 int qd_destroy(qd_env* env) {
+  if (env) {
+    for (auto& f : env->frag)
+      if (f.exec) (void)hipGraphExecDestroy(f.exec);
+    if (env->frag_stream) (void)hipStreamDestroy(env->frag_stream);
+  }
   delete env;
   return QD_OK;
 }
@@ -1156,6 +1176,7 @@ int qd_set_reference(qd_env* env, const double ref_host[4]) {
   QD_NEED(env);
   if (!ref_host) return fail(QD_ERR_INVALID, "null reference");
   for (int i = 0; i < 4; i++) { env->cfg.reference[i] = ref_host[i]; env->ka.ref[i] = (float)ref_host[i]; }
+  for (auto& f : env->frag) f.T = 0;  // captured fragment graphs hold the old reference in their kernel arguments
   return QD_OK;
 }
 
@@ -1269,6 +1290,47 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
 #undef QD_STEP_BLOCK
 #undef QD_STEP_LAUNCH
   QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
+  QD_NEED(env);
+  if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
+  if (T == 0) return QD_OK;
+  if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  const int n = env->ka.n;
+  const size_t D = (size_t)env->D;
+  qd_env::Frag* fr = nullptr;
+  for (auto& f : env->frag)
+    if (f.exec && f.T == T && f.actions == actions && f.obs == obs && f.reward == reward && f.trunc == truncated) fr = &f;
+  if (!fr) {
+    // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured) ...
+    if (!env->frag_stream) QD_HIP(hipStreamCreateWithFlags(&env->frag_stream, hipStreamNonBlocking));
+    fr = &env->frag[0];
+    for (auto& f : env->frag)
+      if (f.T == 0 || !f.exec) { fr = &f; break; } else if (f.used < fr->used) fr = &f;   // a free slot, else the least recently used
+    if (fr->exec) { (void)hipGraphExecDestroy(fr->exec); fr->exec = nullptr; }
+    fr->T = 0;
+    QD_HIP(hipStreamBeginCapture(env->frag_stream, hipStreamCaptureModeThreadLocal));
+    int rc = QD_OK;
+    for (int t = 0; t < T && rc == QD_OK; t++)
+      rc = qd_step(env, actions + (size_t)t * n * 4, (int64_t)n * 4, obs + (size_t)t * n * D, reward + (size_t)t * n,
+                   truncated + (size_t)t * n, env->frag_stream);
+    hipGraph_t graph = nullptr;
+    const hipError_t e = hipStreamEndCapture(env->frag_stream, &graph);
+    if (rc != QD_OK || e != hipSuccess || !graph) {
+      if (graph) (void)hipGraphDestroy(graph);
+      return rc != QD_OK ? rc : fail(QD_ERR_HIP, "hipStreamEndCapture: %s", hipGetErrorString(e));
+    }
+    const hipError_t ei = hipGraphInstantiate(&fr->exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (ei != hipSuccess) { fr->exec = nullptr; return fail(QD_ERR_HIP, "hipGraphInstantiate: %s", hipGetErrorString(ei)); }
+    fr->actions = actions; fr->obs = obs; fr->reward = reward; fr->trunc = truncated; fr->T = T;
+  }
+  fr->used = ++env->frag_clock;
+  // ... and replay in the caller's stream, in order with everything else there.  (Running the graph on the private stream
+  // between cross-stream event waits costs 0.9 us PER KERNEL on this runtime: 5.9 instead of 5.0 us per step.)
+  QD_HIP(hipGraphLaunch(fr->exec, S(stream)));
   return QD_OK;
 }
 

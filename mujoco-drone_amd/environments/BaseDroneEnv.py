@@ -426,6 +426,28 @@ class BaseDroneEnv(_VectorEnvBase):
             trunc.fill_(1)
         return obs, rew, trunc
 
+    def step_fragment_tensor(self, actions, obs, reward, truncated):
+        """T vector_steps (actions [T,N,4] already on the device) written in place into obs [T,N,D], reward [T,N],
+        truncated [T,N]: the per-step kernels replayed from a HIP graph.  The regen rule of vector_step is applied when the
+        fragment ends on the regen boundary; a fragment that would cross it falls back to step-by-step calls."""
+        T = int(actions.shape[0])
+        if self._reference is not self._ref_pushed:
+            self._push_reference()
+        if self._regen_at and self.total_steps + T > self._regen_at:
+            for t in range(T):
+                self.vector_step_tensor(actions[t], out=(obs[t], reward[t], truncated[t]))
+            return obs, reward, truncated
+        self._dev.step_fragment(actions, obs, reward, truncated)
+        self.total_steps += T
+        self._host_cache = self._obs_host = None
+        if self._regen_at and self.total_steps == self._regen_at:
+            self.total_steps = 0
+            self._dev.randomize_params()
+            self._dev.reset(None, want_obs=False)
+            self._dev.observe(obs[T - 1])
+            truncated[T - 1].fill_(1)
+        return obs, reward, truncated
+
     def rollout_tensor(self, actions):
         """T steps in one kernel launch: actions [T,N,4] -> (obs [T,N,D], reward [T,N], truncated [T,N])"""
         self._push_reference()

@@ -137,6 +137,17 @@ class DeviceEnv:
             L.check(rc)
         return obs, reward, truncated
 
+    def step_fragment(self, actions, obs, reward, truncated):
+        """T per-step launches as one HIP graph (captured on first use for these buffers): actions [T,N,4] -> obs [T,N,D],
+        reward [T,N], truncated [T,N], all caller-owned and reused from call to call"""
+        T = int(actions.shape[0])
+        if tuple(actions.shape[1:]) != (self.n, 4) or actions.dtype != torch.float32 or not actions.is_contiguous():
+            raise ValueError("Action dimension mismatch")
+        if tuple(obs.shape) != (T, self.n, self.D) or tuple(reward.shape) != (T, self.n) or tuple(truncated.shape) != (T, self.n):
+            raise ValueError("fragment buffers must be [T,N,D], [T,N], [T,N]")
+        L.check(self.lib.qd_step_fragment(self.handle, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(truncated), self._stream()))
+        return obs, reward, truncated
+
     def rollout(self, actions, obs=None, reward=None, truncated=None):
         """actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N] in one launch."""
         actions = self._f32(actions, tuple(actions.shape))
