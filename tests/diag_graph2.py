@@ -3,7 +3,7 @@ import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
-n, T, reps = 4096, 512, 40
+n, T, reps = 4096, int(os.environ.get("FRAG_T", "512")), int(os.environ.get("FRAG_REPS", "40"))
 env, _ = bench.make_env("config3", n, 42, "cuda:0")
 env.vector_reset_tensor()
 acts = torch.rand((T, n, 4), device="cuda")
