@@ -318,14 +318,21 @@ __device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, 
 
 // copy the wave's staged rows (rows x D floats, contiguous in LDS and in global memory; both 16-byte
 // aligned because a wave starts at a multiple of 64 rows): 16 bytes per lane per instruction
+// Observation rows are written once and never read back by the env: non-temporal stores keep a long fragment (1024 steps
+// x 4096 envs = 369 MB of rows, more than the Infinity Cache) from evicting the state planes and from waiting on HBM write
+// acknowledgements at the end of every launch (5.32 -> 4.89 us per step on 1024-step fragments, 4.75 -> 4.65 on 128-step ones).
+__device__ __forceinline__ void store_streaming(float4* p, float4 v) {
+  typedef float nt_f4 __attribute__((ext_vector_type(4)));
+  __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
+}
 __device__ __forceinline__ void flush_obs(const float* tile, float* dst, int rows, int D) {
   const int lane = threadIdx.x & 63;
   const int total = rows * D, n4 = total >> 2;
   const float4* t4 = reinterpret_cast<const float4*>(tile);
   float4* d4 = reinterpret_cast<float4*>(dst);
 #pragma unroll 3
-  for (int j = lane; j < n4; j += 64) d4[j] = t4[j];
-  for (int j = (n4 << 2) + lane; j < total; j += 64) dst[j] = tile[j];
+  for (int j = lane; j < n4; j += 64) store_streaming(d4 + j, t4[j]);
+  for (int j = (n4 << 2) + lane; j < total; j += 64) __builtin_nontemporal_store(tile[j], dst + j);
 }
 
 // full wavefront, row length known at compile time: all LDS reads are issued before the first store.
@@ -343,8 +350,8 @@ __device__ __forceinline__ void flush_obs_static(const float* tile, float* dst) 
   float4 vt = make_float4(0.f, 0.f, 0.f, 0.f);
   if (TAIL > 0 && lane < TAIL) vt = t4[64 * FULL];
 #pragma unroll
-  for (int k = 0; k < FULL; k++) d4[64 * k] = v[k];
-  if (TAIL > 0 && lane < TAIL) d4[64 * FULL] = vt;
+  for (int k = 0; k < FULL; k++) store_streaming(d4 + 64 * k, v[k]);
+  if (TAIL > 0 && lane < TAIL) store_streaming(d4 + 64 * FULL, vt);
 }
 template <int SPEC> constexpr int spec_obs_dim() { return SPEC == SPEC_RMA ? 22 : SPEC == SPEC_LSTM ? 23 : SPEC == SPEC_SIMPLE ? 6 : 0; }
 
@@ -452,8 +459,8 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
     env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &t);
     QD_STAMP(4);
     store_env(a, i, e);
-    reward[i] = r;
-    trunc[i] = t;
+    __builtin_nontemporal_store(r, reward + i);
+    __builtin_nontemporal_store(t, trunc + i);
   }
   // wave-local staging: the LDS tile is private to the wavefront, so no block barrier is needed
   __builtin_amdgcn_wave_barrier();
@@ -494,8 +501,8 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
       float r;
       uint8_t tr;
       env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &tr);
-      reward[(size_t)t * a.n + i] = r;
-      trunc[(size_t)t * a.n + i] = tr;
+      __builtin_nontemporal_store(r, reward + (size_t)t * a.n + i);
+      __builtin_nontemporal_store(tr, trunc + (size_t)t * a.n + i);
     }
     __builtin_amdgcn_wave_barrier();
     if (wave_base < a.n) {
@@ -575,8 +582,8 @@ __global__ __launch_bounds__(64) void k_rollout_pid(KArgs a, int T, float* __res
       uint8_t tr;
       env_step<LOAD, SPEC>(a, i, e, action, tile + lane * a.D, &r, &tr);
       if (a.auto_reset && tr) pid_reset(c);  // a new episode starts with fresh controller objects
-      reward[(size_t)t * a.n + i] = r;
-      trunc[(size_t)t * a.n + i] = tr;
+      __builtin_nontemporal_store(r, reward + (size_t)t * a.n + i);
+      __builtin_nontemporal_store(tr, trunc + (size_t)t * a.n + i);
     }
     __builtin_amdgcn_wave_barrier();
     if (wave_base < a.n) {
@@ -687,7 +694,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
         fused_env_phase<LOAD, SPEC>(a, i, atile + lane * 4, otile + lane * D, reward + (size_t)t * n + i, trunc + (size_t)t * n + i, trt + lane);
       }
       __builtin_amdgcn_wave_barrier();
-      for (int k = lane; k < rows * D; k += 64) obs[((size_t)t * n + env0) * D + k] = otile[k];
+      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
     }
     __syncthreads();
   }
