@@ -118,3 +118,37 @@ def test_model_matches_closed_forms(orc):
     assert 1e-10 < abs(m.I0full[0] - m.I0full[1]) < 1e-8 and m.I0full[2] > m.I0full[0]
     assert max(abs(m.I0full[3]), abs(m.I0full[4]), abs(m.I0full[5])) < 1e-12
     assert orc.round5g(0.123456789) == 0.12346 and orc.round5g(-1234.5678) == -1234.6 and orc.round5g(2e-5) == 2e-5
+
+
+@pytest.mark.parametrize("axis", [0, 1])
+def test_hanging_load_small_oscillation_matches_damped_pendulum(orc, axis):
+    """Textbook anchor for the load dynamics: under a very heavy hovering drone the load is a damped physical pendulum,
+    theta'' + (c / I) theta' + (m2 g lc / I) theta = 0 with I = I_com + m2 lc^2 about the hinge and c the hinge damping.
+    The simulated period and logarithmic decrement must match the analytic ones (air drag switched off; the drone's recoil
+    and counter-rotation are ~1e-5 with the masses used: with a 1000 kg drone the counter-rotation alone shifts the
+    decrement by 6 %)."""
+    r = RAW.copy(); r[0] = 1.0e6; r[2] = 5.0e6        # a 1000-tonne drone (it must not rotate either: I0 ~ 1e4 kg m^2)
+    m = orc.build_model(r)
+    m.density = m.viscosity = 0.0
+    total = m.m0 + m.m1 + m.m2
+    ctrl = np.full(4, total * abs(m.gravity) / (4 * m.gearF))
+    assert np.all(ctrl < 1.0)
+    qpos = np.zeros(9); qpos[2] = 15; qpos[3] = 1; qpos[7 + axis] = 0.05
+    qvel = np.zeros(8); act = ctrl.copy()
+    h, n = 0.002, 6000
+    th = np.empty(n)
+    for k in range(n):
+        qpos, qvel, act, _ = orc.step(m, h, 1, qpos, qvel, act, ctrl)
+        th[k] = qpos[7 + axis]
+    # the outer hinge (about x) carries the link sphere and the pendulum, the inner one (about y) the pendulum only
+    I = m.I2[axis] + m.m2 * m.lc ** 2 + (m.I1 if axis == 0 else 0.0)
+    k_, c = m.m2 * abs(m.gravity) * m.lc, m.damping
+    wd = np.sqrt(k_ / I - (c / (2 * I)) ** 2)
+    up = np.where((th[:-1] < 0) & (th[1:] >= 0))[0]
+    t_cross = (up + th[up] / (th[up] - th[up + 1])) * h          # interpolated upward zero crossings
+    period = np.mean(np.diff(t_cross))
+    assert abs(period - 2 * np.pi / wd) / (2 * np.pi / wd) < 2e-3
+    peaks = [th[a:b].max() for a, b in zip(up[:-1], up[1:])]
+    decrement = np.mean(np.log(np.array(peaks[:-1]) / np.array(peaks[1:])))
+    assert abs(decrement - c / (2 * I) * 2 * np.pi / wd) / decrement < 2e-2
+    assert abs(qpos[2] - 15) < 1e-3 and np.abs(qpos[:2]).max() < 5e-3     # the heavy drone stays put (mm of drift from the first swing)
