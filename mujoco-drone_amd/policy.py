@@ -6,6 +6,7 @@ Families (eval mode; constructor arguments as in train_PPO.py:39-45):
   "RMA_full"        models/PPO/RMA/RMA_model.py:17-110 with train_adaptation=False
   "RMA_model"       models/PPO/RMA/RMA_model.py:199-292
   "SimpleMLPmodel"  models/PPO/SimpleMLP/SimpleMLP.py:18-98
+  "CustomMLP"       models/PPO/MLP/CustomMLP.py:17-98
   "CNNestimator"    models/PPO/CustomLSTM/StateEstimatorLSTM.py:200-283 with use_estimate=False (train_LSTM.py:51-60; obs_dim =
                     num_states = 23); "CNNestimator_estimate": use_estimate=True, TimeCNN over the 32-step history, incremental
   "RMA_full_adapt"  RMA_full with train_adaptation=True, adapt_seq_len=32 (train_RMA.py:39-45): the adaptation CNN over the
@@ -250,7 +251,27 @@ def _cnn_estimator_estimate(p, D, ns, npar, na):
     return dict(widths=[32, 32, 256, 128, 160, 160, 160], logits=(P, 0, nl), value=(X, 0))
 
 
-_FAMILIES = {"CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
+def _custom_mlp(p, D, ns, npar, na):
+    """CustomMLP (models/PPO/MLP/CustomMLP.py:17-98): BatchNorm -> 256 -> 128 -> 128 -> 96 -> BatchNorm trunk on cat(obs, prev_actions)"""
+    X, P, A, B = 0, 1, 2, 3
+    p.copy_obs(0, D, X, 0); p.copy_prev(na, X, D)
+    p.bn("_hidden_layers.0", X, 0)
+    p.fc("_hidden_layers.1", (X, 0), (A, 0), "tanh")
+    p.fc("_hidden_layers.2", (A, 0), (B, 0), "tanh")
+    p.fc("_hidden_layers.3", (B, 0), (A, 0), "tanh")
+    p.fc("_hidden_layers.4", (A, 0), (B, 0), "tanh")
+    p.bn("_hidden_layers.5", B, 0)
+    p.fc("_logits.0", (B, 0), (A, 0), "tanh")
+    p.fc("_logits.1", (A, 0), (A, 64), "tanh")
+    nl = p.fc("_logits.2", (A, 64), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[max(32, D + na), 16, 256, 128], logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"CustomMLP": _custom_mlp, "CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 
 
 def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):

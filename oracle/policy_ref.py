@@ -106,7 +106,15 @@ def cnn_estimator_hist(w, obs_history, action_history, num_states=23):
     return _seq(w, "_logits", feat, [None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0], est
 
 
-FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp}
+def custom_mlp(w, obs, prev_actions):
+    """CustomMLP.forward (models/PPO/MLP/CustomMLP.py:75-98): one trunk on cat(obs, prev_actions) with BatchNorm at both ends,
+    actor and critic heads on its features"""
+    x = np.concatenate([np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)], axis=-1)
+    feat = _seq(w, "_hidden_layers", x, ["bn"] + ["tanh"] * 4 + ["bn"])
+    return _seq(w, "_logits", feat, ["tanh", "tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]
+
+
+FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp, "custom_mlp": custom_mlp}
 
 
 def beta_params(logits):

@@ -118,6 +118,7 @@ def main():
     import gymnasium
     from models.PPO.RMA.RMA_model import RMA_full, RMA_model
     from models.PPO.SimpleMLP.SimpleMLP import SimpleMLPmodel
+    from models.PPO.MLP.CustomMLP import CustomMLP
     from distributions import MyBetaDist
 
     gen = torch.Generator().manual_seed(20250614)
@@ -130,7 +131,7 @@ def main():
     obs[:, 16:] = torch.tensor([1, 0.17, 7, 0.01, 1.2, 0.3]) * (1 + 0.1 * torch.randn((n, 6), generator=gen))
     prev = torch.rand((n, 4), generator=gen)
     out = {"obs": obs.numpy(), "prev_actions": prev.numpy()}
-    for tag, cls in (("rma_full", RMA_full), ("rma_model", RMA_model), ("simple_mlp", SimpleMLPmodel)):
+    for tag, cls in (("rma_full", RMA_full), ("rma_model", RMA_model), ("simple_mlp", SimpleMLPmodel), ("custom_mlp", CustomMLP)):
         torch.manual_seed(7)
         model = cls(obs_space, act_space, 8, {"custom_model_config": cc}, tag)
         _randomise(model, gen)

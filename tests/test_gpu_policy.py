@@ -11,6 +11,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 HERE = os.path.dirname(os.path.abspath(__file__))
 TAGS = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "SimpleMLPmodel"}
+ALL_TAGS = dict(TAGS, custom_mlp="CustomMLP")          # CustomMLP has no compile-time specialisation: always the interpreter
 
 
 @pytest.fixture(scope="module")
@@ -35,11 +36,11 @@ def kernel(request, monkeypatch):
     return request.param
 
 
-@pytest.mark.parametrize("tag", list(TAGS))
+@pytest.mark.parametrize("tag", list(ALL_TAGS))
 def test_policy_forward_vs_reference_models(PG, tag, kernel):
     from mujoco_drone_amd.policy import DevicePolicy
-    pol = DevicePolicy(TAGS[tag], weights_of(PG, tag))
-    assert (pol.kernel > 0) == (kernel == "specialised")
+    pol = DevicePolicy(ALL_TAGS[tag], weights_of(PG, tag))
+    assert (pol.kernel > 0) == (kernel == "specialised" and tag in TAGS)
     obs, prev = torch.tensor(PG["obs"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda")
     act, logits, value = pol.forward(obs, prev, want_logits=True, want_value=True)
     np.testing.assert_allclose(logits.cpu().numpy(), PG[tag + "_logits"], atol=2e-5)

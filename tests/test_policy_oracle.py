@@ -17,7 +17,7 @@ def weights_of(PG, tag):
     return {k: PG[tag + "/" + k] for k in PG[tag + "_keys"]}
 
 
-@pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp"])
+@pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp", "custom_mlp"])
 def test_policy_oracle_vs_reference_models(PG, tag):
     from oracle import policy_ref as P
     w = weights_of(PG, tag)
@@ -28,10 +28,10 @@ def test_policy_oracle_vs_reference_models(PG, tag):
     np.testing.assert_allclose(P.beta_logp(PG[tag + "_logits"], PG[tag + "_action"]), PG[tag + "_logp"], atol=2e-5)
 
 
-FAMILY_OF = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "SimpleMLPmodel"}
+FAMILY_OF = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "SimpleMLPmodel", "custom_mlp": "CustomMLP"}
 
 
-@pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp"])
+@pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp", "custom_mlp"])
 def test_policy_programs_compile_on_the_host(PG, tag):
     """state dict -> layer program -> qd_policy_packed_bytes (host-only entry point of the C ABI): the program passes
     the library's validation and the packed blob has the size the padded 16x16 tiling implies"""
