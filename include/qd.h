@@ -212,11 +212,16 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
  *                      (of this step's bank), oldest first; the fill values for envs at an episode start
  *   QD_POL_RING_PUSH : this step's slot of ring `out_buf` = buf[in_buf][in_off : + width]; at an episode start every
  *                      other slot of the ring is set to the fill values
+ *   QD_POL_LSTM_CELL : torch.nn.LSTM's cell update for one step: gates = in slice [4H] in the order (i, f, g, o), H = out_dim;
+ *                      out slice [H] <- h' = sigmoid(o) tanh(c'), the H floats right after it hold c and are updated in
+ *                      place, c' = sigmoid(f) c + sigmoid(i) tanh(g).  (The gates come from a DENSE op over [x | h] with
+ *                      the weights [W_ih | W_hh] and bias b_ih + b_hh; h and c travel between steps in rings of one row.)
  * (ring ops need the step `counter` of qd_policy_act: consecutive calls must pass consecutive counters)
  * Outputs: logits[N, n_logits] (n_logits = 2 * act_dim), value[N] (if the program has a value slot) and
  * actions[N, act_dim] = alpha / (alpha + beta) with (alpha, beta) = softplus(clamp(logits, +-50)) + 1.
  * The caller owns the device buffer the packed weights live in (qd_policy_packed_bytes). */
-enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3, QD_POL_RING_LOAD = 4, QD_POL_RING_PUSH = 5 };
+enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PREV = 3, QD_POL_RING_LOAD = 4, QD_POL_RING_PUSH = 5,
+       QD_POL_LSTM_CELL = 6 };
 enum { QD_ACT_NONE = 0, QD_ACT_TANH = 1, QD_ACT_RELU = 2 };
 enum { QD_POL_VALUE_ONLY = 1 };
 typedef struct qd_policy qd_policy;

@@ -68,7 +68,7 @@ class QdPolicyDesc(C.Structure):
                 ("aux_buf", C.c_int32), ("aux_off", C.c_int32), ("aux_dim", C.c_int32), ("reserved1", C.c_int32)]
 
 
-POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH = 0, 1, 2, 3, 4, 5
+POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH, POL_LSTM_CELL = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 POL_VALUE_ONLY = 1
 

@@ -29,7 +29,7 @@ constexpr int POL_MAX_OPS = 32, POL_MAX_BUFS = 8, POL_MAX_RINGS = 4, POL_WAVES =
 constexpr int POL_KC = 4;       // k-blocks (of 16 inputs) per step
 constexpr int POL_DESC = 16;    // ints per op descriptor
 constexpr int POL_SDESC = 32;   // ints per step descriptor
-enum { POL_DENSE = 0, POL_AFFINE = 1, POL_COPY_OBS = 2, POL_COPY_PREV = 3, POL_RING_LOAD = 4, POL_RING_PUSH = 5 };
+enum { POL_DENSE = 0, POL_AFFINE = 1, POL_COPY_OBS = 2, POL_COPY_PREV = 3, POL_RING_LOAD = 4, POL_RING_PUSH = 5, POL_LSTM_CELL = 6 };
 enum { POL_ACT_NONE = 0, POL_ACT_TANH = 1, POL_ACT_RELU = 2 };
 enum { POL_FLAG_VALUE_ONLY = 1 };  // the op only feeds the value head: skipped when no value output is requested
 enum { POL_STEP_FIRST = 1, POL_STEP_LAST = 2, POL_STEP_VALUE_ONLY = 4 };
@@ -242,6 +242,20 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
       for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
         const int r = k / n, c = k - r * n;
         b[r * ld + c] = fmaf(b[r * ld + c], sc[c], sh[c]);
+      }
+    } else if (kind == POL_LSTM_CELL) {
+      // torch.nn.LSTM cell, gate order (i, f, g, o); c sits right after h in the output buffer
+      const float* gt = lds + od[OD_IN];
+      float* hc = lds + od[OD_OUT];
+      const int ldg = od[OD_LD_IN], ldh = od[OD_LD_OUT], H = od[OD_COUNT];
+      for (int k = tid; k < POL_TILE * H; k += POL_THREADS) {
+        const int r = k / H, j = k - r * H;
+        const float* g4 = gt + r * ldg + j;
+        const float si = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[0])), sf = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[H]));
+        const float so = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[3 * H]));
+        const float cn = fmaf(sf, hc[r * ldh + H + j], si * pol_act(g4[2 * H], POL_ACT_TANH));
+        hc[r * ldh + H + j] = cn;
+        hc[r * ldh + j] = so * pol_act(cn, POL_ACT_TANH);
       }
     } else if (kind == POL_RING_LOAD || kind == POL_RING_PUSH) {
       // history rings: slot written at step t is t mod rows (period 2: bank t & 1, slot (t >> 1) mod rows)

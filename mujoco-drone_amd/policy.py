@@ -9,6 +9,8 @@ Families (eval mode; constructor arguments as in train_PPO.py:39-45):
   "CustomMLP"       models/PPO/MLP/CustomMLP.py:17-98
   "CNNestimator"    models/PPO/CustomLSTM/StateEstimatorLSTM.py:200-283 with use_estimate=False (train_LSTM.py:51-60; obs_dim =
                     num_states = 23); "CNNestimator_estimate": use_estimate=True, TimeCNN over the 32-step history, incremental
+  "LSTMestimator"   models/PPO/CustomLSTM/StateEstimatorLSTM.py:15-147 (obs_dim 19), use_estimate=False; "LSTMestimator_estimate":
+                    the nn.LSTM pendulum-state estimator in the loop (h, c and the previous observation kept per env)
   "RMA_full_adapt"  RMA_full with train_adaptation=True, adapt_seq_len=32 (train_RMA.py:39-45): the adaptation CNN over the
                     32-step history, evaluated incrementally from per-env rings (pass consecutive `counter`s; call
                     reset_state at the start; envs flagged in prev_truncated restart their history by themselves)
@@ -80,6 +82,10 @@ class _Program:
     def ring_push(self, src, ring):
         width = self.rings[ring][1]
         self.ops.append(L.QdPolicyOp(L.POL_RING_PUSH, src[0], src[1], width, ring, 0, width, 0, self.flags, 0, 0, 0))
+
+    def lstm_cell(self, gates, hc, hidden):
+        """gates (buf, off) [4H] -> h' at hc (buf, off) [H], c updated in place right behind it"""
+        self.ops.append(L.QdPolicyOp(L.POL_LSTM_CELL, gates[0], gates[1], 4 * hidden, hc[0], hc[1], hidden, 0, self.flags, 0, 0, 0))
 
     def bn(self, prefix, buf, off):
         """eval-mode BatchNorm1d `prefix` in place"""
@@ -271,7 +277,46 @@ def _custom_mlp(p, D, ns, npar, na):
     return dict(widths=[max(32, D + na), 16, 256, 128], logits=(P, 0, nl), value=(X, 0))
 
 
-_FAMILIES = {"CustomMLP": _custom_mlp, "CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
+def _lstm_estimator(p, D, ns, npar, na, use_estimate):
+    """LSTMestimator (StateEstimatorLSTM.py:15-147): observation = 15 drone values + 4 pendulum values (D = 19); the policy sees
+    cat(o_t[:15], a_{t-1}, pendulum) where pendulum is the ground truth (use_estimate=False: no recurrence on the action path) or
+    LSTMestimatorModule2's estimate from (o_{t-1}[:15], o_t[:15], a_{t-1}) (:174-197: MLP1 -> nn.LSTM(32, 32) -> MLP2(f + y)).
+    h, c and the previous observation travel between steps in one-row rings (zeros at an episode start, as get_initial_state
+    and RLlib's zero padding give)."""
+    X, P, A, B, IN, S, G = 0, 1, 2, 3, 4, 5, 6
+    w, em, no, H = p.w, "estimation_module.", D - 4, 32
+    p.copy_obs(0, no, X, 0); p.copy_prev(na, X, no)
+    if not use_estimate:
+        p.copy_obs(no, 4, X, no + na)
+        widths = [32, 16, 256, 128]
+    else:
+        r_o, r_h, r_c = p.ring(1, no, 1, np.zeros(no)), p.ring(1, H, 1, np.zeros(H)), p.ring(1, H, 1, np.zeros(H))
+        p.ring_load(r_o, (IN, 0)); p.ring_load(r_h, (S, H)); p.ring_load(r_c, (S, 2 * H))
+        p.copy_obs(0, no, IN, no); p.copy_prev(na, IN, 2 * no)                      # :77-78 cat(prev_o[:, :, :15].flatten(1), prev_a)
+        p.fc(em + "MLP1.0", (IN, 0), (A, 0), "tanh")
+        p.fc(em + "MLP1.1", (A, 0), (S, 0), "tanh")                                  # y
+        Wg = np.concatenate([w[em + "LSTM.weight_ih_l0"], w[em + "LSTM.weight_hh_l0"]], axis=1)      # gates over [y | h]
+        p.dense(Wg, w[em + "LSTM.bias_ih_l0"] + w[em + "LSTM.bias_hh_l0"], (S, 0), (G, 0), None)
+        p.ring_push((IN, no), r_o)                                                  # o_t is the next step's o_{t-1}
+        p.lstm_cell((G, 0), (S, H), H)
+        p.ring_push((S, H), r_h); p.ring_push((S, 2 * H), r_c)
+        W2 = w[em + "MLP2.0._model.0.weight"]
+        p.dense(np.concatenate([W2, W2], axis=1), w[em + "MLP2.0._model.0.bias"], (S, 0), (A, 0), "tanh")   # MLP2(f + y), f = h'
+        p.fc(em + "MLP2.1", (A, 0), (X, no + na), None)
+        widths = [32, 16, 256, 128, 48, 96, 128]
+    p.fc("_hidden.0", (X, 0), (A, 0), "tanh")
+    p.fc("_hidden.1", (A, 0), (B, 0), "tanh")
+    nl = p.fc("_logits.0", (B, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=widths, logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"LSTMestimator": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, False),
+             "LSTMestimator_estimate": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, True),
+             "CustomMLP": _custom_mlp, "CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 
 
 def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):

@@ -114,6 +114,35 @@ def custom_mlp(w, obs, prev_actions):
     return _seq(w, "_logits", feat, ["tanh", "tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]
 
 
+def lstm_estimator(w, obs_seq, action_seq, use_estimate=True):
+    """LSTMestimator.forward_rnn (StateEstimatorLSTM.py:100-118) over whole episodes: obs_seq [B, T, 19], action_seq [B, T, 4]
+    (the action taken AFTER each observation); LSTMestimatorModule2 (:174-197) = MLP1 -> nn.LSTM(32, 32) (gate order i, f, g, o)
+    -> MLP2(f + y), zero initial state, zero o_{t-1} / a_{t-1} at the episode start; returns (logits [B,T,8], value [B,T],
+    estimates [B,T,4])"""
+    o, a = np.asarray(obs_seq, np.float64), np.asarray(action_seq, np.float64)
+    Bn, Tn, _ = o.shape
+    f64 = lambda k: np.asarray(w[k], np.float64)
+    em = "estimation_module."
+    Wih, Whh, b = f64(em + "LSTM.weight_ih_l0"), f64(em + "LSTM.weight_hh_l0"), f64(em + "LSTM.bias_ih_l0") + f64(em + "LSTM.bias_hh_l0")
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    h, c = np.zeros((Bn, 32)), np.zeros((Bn, 32))
+    logits, value, est = [], [], []
+    for t in range(Tn):
+        o_prev = o[:, t - 1, :15] if t > 0 else np.zeros((Bn, 15))
+        a_prev = a[:, t - 1] if t > 0 else np.zeros((Bn, 4))
+        x = np.concatenate([o_prev, o[:, t, :15], a_prev], axis=-1)
+        y = _seq(w, em + "MLP1", x, ["tanh", "tanh"])
+        g = y @ Wih.T + h @ Whh.T + b
+        i_, f_, g_, o_ = sig(g[:, :32]), sig(g[:, 32:64]), np.tanh(g[:, 64:96]), sig(g[:, 96:])
+        c = f_ * c + i_ * g_
+        h = o_ * np.tanh(c)
+        e = _seq(w, em + "MLP2", h + y, ["tanh", None])
+        pend = e if use_estimate else o[:, t, 15:]
+        feat = _seq(w, "_hidden", np.concatenate([x[:, -19:], pend], axis=-1), ["tanh", "tanh"])
+        logits.append(_seq(w, "_logits", feat, [None])); value.append(_seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0]); est.append(e)
+    return np.stack(logits, 1), np.stack(value, 1), np.stack(est, 1)
+
+
 FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp, "custom_mlp": custom_mlp}
 
 

@@ -216,6 +216,39 @@ def main():
         out[tag + "_keys"] = np.array(list(sd.keys()))
         for k, v in sd.items():
             out[tag + "/" + k] = v.numpy()
+    # LSTMestimator (StateEstimatorLSTM.py:15-147) with the nn.LSTM pendulum-state estimator in the loop.  Its forward() only
+    # assembles `inputs` from the view requirements (prev_o = [o_{t-1}, o_t], prev_a) through ray's add_time_dimension; the
+    # network proper is forward_rnn(inputs [B, T, 34], state), called here directly on explicit sequences.
+    from models.PPO.CustomLSTM.StateEstimatorLSTM import LSTMestimator
+    D19 = 19
+    obs_space19 = gymnasium.spaces.Box(low=-np.inf, high=np.inf, shape=(D19,))
+    torch.manual_seed(17)
+    model = LSTMestimator(obs_space19, act_space, 8, {"custom_model_config": {'num_states': 19, 'num_actions': 4, 'use_estimate': True,
+                                                                              'train_estimator': False}}, "lstm_est")
+    _randomise(model, gen)
+    with torch.no_grad():
+        for name, prm in model.estimation_module.LSTM.named_parameters():
+            if "bias" in name:
+                prm.copy_(torch.randn(prm.shape, generator=gen) * 0.1)
+    model.eval()
+    Bn, Tn = 12, 24
+    o_seq = torch.randn((Bn, Tn, D19), generator=gen) * 1.2
+    a_seq = torch.rand((Bn, Tn, 4), generator=gen)                     # a_seq[:, t] = the action taken after o_seq[:, t]
+    o_prev = torch.cat([torch.zeros((Bn, 1, 15)), o_seq[:, :-1, :15]], dim=1)       # zero before the episode start
+    a_prev = torch.cat([torch.zeros((Bn, 1, 4)), a_seq[:, :-1]], dim=1)
+    inputs = torch.cat([o_prev, o_seq[:, :, :15], a_prev], dim=-1)                   # :77-78
+    model.gt_pendulum_states = o_seq[:, :, 15:]
+    with torch.no_grad():
+        logits, state_out = model.forward_rnn(inputs, [torch.zeros((Bn, 32)), torch.zeros((Bn, 32))], None, False)
+        value = model.value_function()
+    out["lstm_est_obs_seq"], out["lstm_est_action_seq"] = o_seq.numpy(), a_seq.numpy()
+    out["lstm_est_logits"], out["lstm_est_value"] = logits.numpy(), value.numpy().reshape(Bn, Tn)
+    out["lstm_est_estimates"] = model.pendulum_state_estimates.numpy()
+    out["lstm_est_h"], out["lstm_est_c"] = state_out[0].numpy(), state_out[1].numpy()
+    sd = model.state_dict()
+    out["lstm_est_keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        out["lstm_est/" + k] = v.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

@@ -443,3 +443,47 @@ def test_policy_api_error_paths(PG):
     o = env.vector_reset_tensor()
     with pytest.raises(ValueError):
         pol.rollout(env._dev, 2, o)
+
+
+def test_lstm_estimator_policy_vs_reference_model(PG):
+    """LSTMestimator with the nn.LSTM estimate in the loop: the device steps it one observation at a time (h, c and the
+    previous observation in per-env rings) and must reproduce the reference model's own outputs over whole 24-step
+    episodes; then episodes restarted in the middle against the float64 oracle"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    w = weights_of(PG, "lstm_est")
+    pol = DevicePolicy("LSTMestimator_estimate", w, obs_dim=19, num_states=19)
+    assert pol.kernel == 0 and pol.has_history
+    o, a = PG["lstm_est_obs_seq"], PG["lstm_est_action_seq"]
+    Bn, Tn = o.shape[:2]
+    pol.reset_state(Bn)
+    for t in range(Tn):
+        prev = torch.tensor(a[:, t - 1], device="cuda") if t > 0 else None
+        act, logits, value = pol.forward(torch.tensor(o[:, t], device="cuda"), prev, None, counter=t, want_logits=True, want_value=True)
+        np.testing.assert_allclose(logits.cpu().numpy(), PG["lstm_est_logits"][:, t], atol=3e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(value.cpu().numpy(), PG["lstm_est_value"][:, t], atol=3e-5)
+    # restart every third env at step 9: its h, c, previous observation and previous action go back to zero
+    rng = np.random.default_rng(2)
+    n, T2 = 30, 20
+    obs = rng.normal(size=(n, T2, 19)).astype(np.float32); acts = rng.uniform(0, 1, (n, T2, 4)).astype(np.float32)
+    fresh9 = np.arange(n) % 3 == 0
+    pol.reset_state(n)
+    got = []
+    for t in range(T2):
+        fr = fresh9 if t == 9 else np.zeros(n, bool)
+        prev = acts[:, t - 1] * (1 - fr[:, None]) if t > 0 else np.zeros((n, 4), np.float32)
+        _, lg = pol.forward(torch.tensor(obs[:, t], device="cuda"), torch.tensor(prev.astype(np.float32), device="cuda"),
+                            torch.tensor(fr.astype(np.uint8), device="cuda") if t > 0 else None, counter=100 + t, want_logits=True)
+        got.append(lg.cpu().numpy())
+    got = np.stack(got, 1)
+    want_all, _, _ = P.lstm_estimator(w, obs, acts)
+    want_restart, _, _ = P.lstm_estimator(w, obs[fresh9, 9:], acts[fresh9, 9:])
+    np.testing.assert_allclose(got[~fresh9], want_all[~fresh9], atol=3e-5)
+    np.testing.assert_allclose(got[fresh9, :9], want_all[fresh9, :9], atol=3e-5)
+    np.testing.assert_allclose(got[fresh9, 9:], want_restart, atol=3e-5)
+    # without the estimate the network is feed-forward on the 19-value observation
+    ff = DevicePolicy("LSTMestimator", w, obs_dim=19, num_states=19)
+    assert not ff.has_history
+    _, lg = ff.forward(torch.tensor(obs[:, 3], device="cuda"), torch.tensor(acts[:, 2], device="cuda"), want_logits=True)
+    want_ff, _, _ = P.lstm_estimator(w, obs[:, 2:4], acts[:, 2:4], use_estimate=False)
+    np.testing.assert_allclose(lg.cpu().numpy(), want_ff[:, 1], atol=3e-5)

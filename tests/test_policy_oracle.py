@@ -85,3 +85,12 @@ def test_cnn_estimator_oracle_vs_reference_model(PG):
     np.testing.assert_allclose(est, PG["cnn_est_hist_estimate"], atol=3e-6)
     np.testing.assert_allclose(logits, PG["cnn_est_hist_logits"], atol=3e-6)
     np.testing.assert_allclose(value, PG["cnn_est_hist_value"], atol=3e-6)
+
+
+def test_lstm_estimator_oracle_vs_reference_model(PG):
+    """LSTMestimator.forward_rnn with the nn.LSTM estimate in the loop, 24-step episodes from the zero initial state"""
+    from oracle import policy_ref as P
+    logits, value, est = P.lstm_estimator(weights_of(PG, "lstm_est"), PG["lstm_est_obs_seq"], PG["lstm_est_action_seq"])
+    np.testing.assert_allclose(est, PG["lstm_est_estimates"], atol=3e-6)
+    np.testing.assert_allclose(logits, PG["lstm_est_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["lstm_est_value"], atol=3e-6)
