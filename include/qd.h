@@ -135,6 +135,10 @@ int qd_reset_data(qd_env* env, void* stream);
 
 /* env.reference = [...] (evaluation.py:48,66) */
 int qd_set_reference(qd_env* env, const double ref_host[4]);
+/* evaluate_trajectory (evaluation.py:38-72): a waypoint list for the next qd_rollout_policy calls -- step k of a rollout
+ * runs (and is rewarded) under traj_host[k] (the last waypoint is held past the end), while its action was computed from
+ * the observation under the previous one, as `env.reference = x` before `vector_step` gives.  T = 0 clears the schedule. */
+int qd_set_reference_schedule(qd_env* env, const double* traj_host, int T);
 /* extension for per-env moving waypoints (BASELINE config 5): ref[N,4] */
 int qd_set_reference_per_env(qd_env* env, const float* ref, void* stream);
 

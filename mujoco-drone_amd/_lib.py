@@ -87,6 +87,7 @@ SIGNATURES = {
     "qd_reset_data": (_I, [_VP, _VP]),
     "qd_set_reference": (_I, [_VP, _D4]),
     "qd_set_reference_per_env": (_I, [_VP, _VP, _VP]),
+    "qd_set_reference_schedule": (_I, [_VP, _D4, _I]),
     "qd_randomize_params": (_I, [_VP, _VP]),
     "qd_set_params": (_I, [_VP, _VP, _VP]),
     "qd_get_params": (_I, [_VP, _VP, _VP]),

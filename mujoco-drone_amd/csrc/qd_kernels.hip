@@ -977,6 +977,8 @@ struct qd_env {
   Frag frag[FRAGS];
   unsigned long long frag_clock = 0;
   hipStream_t frag_stream = nullptr;
+  // qd_set_reference_schedule: waypoint k is the reference of the k-th step of the next policy rollout
+  std::vector<double> ref_schedule;
 };
 
 static thread_local char g_err[512] = "";
@@ -1184,6 +1186,13 @@ int qd_set_reference(qd_env* env, const double ref_host[4]) {
   if (!ref_host) return fail(QD_ERR_INVALID, "null reference");
   for (int i = 0; i < 4; i++) { env->cfg.reference[i] = ref_host[i]; env->ka.ref[i] = (float)ref_host[i]; }
   for (auto& f : env->frag) f.T = 0;  // captured fragment graphs hold the old reference in their kernel arguments
+  return QD_OK;
+}
+
+int qd_set_reference_schedule(qd_env* env, const double* traj_host, int T) {
+  QD_NEED(env);
+  if (T < 0 || (T > 0 && !traj_host)) return fail(QD_ERR_INVALID, "bad reference schedule");
+  env->ref_schedule.assign(traj_host, traj_host + (size_t)4 * T);
   return QD_OK;
 }
 

@@ -108,8 +108,12 @@ class BaseDroneEnv(_VectorEnvBase):
         # --- the key reads of BaseDroneEnv.py:60-106, same defaults -------------------
         self.controlled = config.get('controlled', False)
         if self.controlled:
-            raise NotImplementedError("joystick reference control (BaseDroneEnv.py:151-172) is a human-in-the-loop UI "
-                                      "and is not part of the GPU env")
+            # BaseDroneEnv.py:69-74: the reference looks for a PS4/PS5 joystick and, finding none, switches reference
+            # control off and carries on.  The GPU env never has one (a human-in-the-loop UI is not part of it), so an
+            # evaluation config with controlled=True (train_RMA.py:80) behaves exactly like the reference on a headless box.
+            print('Initializing controller')
+            print('Disabling reference control')
+            self.controlled = False
         self.render_mode = None  # rendering is out of scope; render() is a no-op
         for attr, (key, default) in _ATTR_DEFAULTS.items():
             setattr(self, attr, config.get(key, default))

@@ -487,3 +487,39 @@ def test_lstm_estimator_policy_vs_reference_model(PG):
     _, lg = ff.forward(torch.tensor(obs[:, 3], device="cuda"), torch.tensor(acts[:, 2], device="cuda"), want_logits=True)
     want_ff, _, _ = P.lstm_estimator(w, obs[:, 2:4], acts[:, 2:4], use_estimate=False)
     np.testing.assert_allclose(lg.cpu().numpy(), want_ff[:, 1], atol=3e-5)
+
+
+def test_evaluate_trajectory_like_evaluation_py(PG, golden_traj=None):
+    """evaluation.py:38-72 as one device-side rollout: waypoint k is set before step k (the action for that step comes from the
+    observation under the previous waypoint); against the same loop written out with env.reference = x per step"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.evaluation import evaluate_trajectory, gen_step_trajectory, gen_ramp_trajectory, gen_circle_trajectory
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    G = np.load(os.path.join(HERE, "golden", "reference_vectors.npz"))
+    _, st = gen_step_trajectory(G["traj_step_args"][0], G["traj_step_args"][1], G["traj_start"], G["traj_end"])
+    _, rp = gen_ramp_trajectory(G["traj_ramp_args"][0], G["traj_ramp_args"][1], G["traj_start"], G["traj_end"])
+    _, ci = gen_circle_trajectory(2.0, 0.5, 1.0, 15.0)
+    np.testing.assert_array_equal(st, G["traj_step"]); np.testing.assert_allclose(rp, G["traj_ramp"], atol=1e-13)
+    np.testing.assert_allclose(ci, G["traj_circle"], atol=1e-13)         # the generators equal the reference's outputs
+    pol = DevicePolicy("RMA_full", weights_of(PG, "rma_full"))
+    cfg = dict(base_config, num_drones=8, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=2048, max_distance=1e9, controlled=True)
+    traj = rp[:60]
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    observations, actions, rewards, out = evaluate_trajectory(e1, pol, traj)
+    assert len(observations) == len(traj) + 1 and len(actions) == len(rewards) == len(traj)
+    e2.reference = list(traj[0])
+    obs = e2.vector_reset_tensor().clone()
+    np.testing.assert_allclose(observations[0], obs[0].cpu().numpy(), atol=1e-6)
+    prev, tr = None, None
+    for k, x in enumerate(traj):
+        a = pol.forward(obs, prev, tr)
+        e2.reference = list(x)
+        ob, rw, trn = e2.vector_step_tensor(a)
+        obs, prev, tr = ob.clone(), a, trn.clone()
+        np.testing.assert_allclose(observations[k + 1], obs[0].cpu().numpy(), atol=2e-5, err_msg="k=%d" % k)
+        np.testing.assert_allclose(actions[k], a[0].cpu().numpy(), atol=2e-5)
+        assert abs(rewards[k] - float(rw[0])) < 2e-5
+    assert list(e1.reference) == [float(v) for v in traj[-1]]
