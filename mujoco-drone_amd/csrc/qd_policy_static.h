@@ -169,7 +169,31 @@ struct ArchCnnEstHist {  // CNNestimator, use_estimate=True: TimeCNN over the 32
       7, {32, 32, 256, 128, 160, 160, 160}, 23, 4, SP, 0, 8, SX, 0,
       3, {{5, 32, 1}, {4, 32, 2}, {9, 16, 2}}};
 };
-// (the windowed networks and SimpleMLPmodel / CNNestimator declare no auxiliary slice)
+struct ArchCustomMlp {  // models/PPO/MLP/CustomMLP.py:17-98
+  static constexpr SProg prog = {14,
+      {{POL_COPY_OBS, 0, 0, 22, SX, 0, 22, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 22, 4, 0, 0}, {POL_AFFINE, SX, 0, 26, SX, 0, 26, 0, 0},
+       {POL_DENSE, SX, 0, 26, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, 0},
+       {POL_DENSE, SA, 0, 128, SB, 0, 96, TANH, 0}, {POL_AFFINE, SB, 0, 96, SB, 0, 96, 0, 0},
+       {POL_DENSE, SB, 0, 96, SA, 0, 64, TANH, 0}, {POL_DENSE, SA, 0, 64, SA, 64, 64, TANH, 0}, {POL_DENSE, SA, 64, 64, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 96, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      4, {32, 16, 256, 128}, 22, 4, SP, 0, 8, SX, 0, 0, {}};
+};
+constexpr int SIN = 4, SS = 5, SG = 6;
+struct ArchLstmEst {  // LSTMestimator with the nn.LSTM estimate (StateEstimatorLSTM.py:15-197); see policy.py:_lstm_estimator
+  static constexpr SProg prog = {22,
+      {{POL_COPY_OBS, 0, 0, 15, SX, 0, 15, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SX, 15, 4, 0, 0},
+       {POL_RING_LOAD, 0, 0, 15, SIN, 0, 15, 0, 0}, {POL_RING_LOAD, 1, 0, 32, SS, 32, 32, 0, 0}, {POL_RING_LOAD, 2, 0, 32, SS, 64, 32, 0, 0},
+       {POL_COPY_OBS, 0, 0, 15, SIN, 15, 15, 0, 0}, {POL_COPY_PREV, 0, 0, 4, SIN, 30, 4, 0, 0},
+       {POL_DENSE, SIN, 0, 34, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SS, 0, 32, TANH, 0}, {POL_DENSE, SS, 0, 64, SG, 0, 128, 0, 0},
+       {POL_RING_PUSH, SIN, 15, 15, 0, 0, 15, 0, 0}, {POL_LSTM_CELL, SG, 0, 128, SS, 32, 32, 0, 0},
+       {POL_RING_PUSH, SS, 32, 32, 1, 0, 32, 0, 0}, {POL_RING_PUSH, SS, 64, 32, 2, 0, 32, 0, 0},
+       {POL_DENSE, SS, 0, 64, SA, 0, 32, TANH, 0}, {POL_DENSE, SA, 0, 32, SX, 19, 4, 0, 0},
+       {POL_DENSE, SX, 0, 23, SA, 0, 256, TANH, 0}, {POL_DENSE, SA, 0, 256, SB, 0, 128, TANH, 0}, {POL_DENSE, SB, 0, 128, SP, 0, 8, 0, 0},
+       {POL_DENSE, SB, 0, 128, SA, 0, 128, TANH, SV}, {POL_DENSE, SA, 0, 128, SA, 128, 128, TANH, SV}, {POL_DENSE, SA, 128, 128, SX, 0, 1, 0, SV}},
+      7, {32, 16, 256, 128, 48, 96, 128}, 19, 4, SP, 0, 8, SX, 0,
+      3, {{1, 15, 1}, {1, 32, 1}, {1, 32, 1}}};
+};
+// (the windowed networks and SimpleMLPmodel / CustomMLP / CNNestimator / LSTMestimator declare no auxiliary slice)
 
 // ---- the specialised kernel ----
 struct SCtx {
@@ -347,6 +371,19 @@ __device__ __forceinline__ void s_other(const SCtx& c) {
         ring[(bank * R + slot_new) * W + col] = c.lds[in_base + r * ld_in + col];
       }
     }
+  } else if constexpr (op.kind == POL_LSTM_CELL) {
+    // torch.nn.LSTM cell, gate order (i, f, g, o); c sits right after h in the output buffer
+    constexpr int H = op.out_dim, ldg = sp_ld(A::prog, op.in_buf), g_base = sp_base(A::prog, op.in_buf) + op.in_off;
+    for (int k = c.tid; k < POL_TILE * H; k += POL_THREADS) {
+      const int r = k / H, j = k - r * H;
+      const float* g4 = c.lds + g_base + r * ldg + j;
+      float* hc = c.lds + out_base + r * ld + j;
+      const float si = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[0])), sf = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[H]));
+      const float so = __builtin_amdgcn_rcpf(1.0f + __expf(-g4[3 * H]));
+      const float cn = fmaf(sf, hc[H], si * pol_act(g4[2 * H], POL_ACT_TANH));
+      hc[H] = cn;
+      hc[0] = so * pol_act(cn, POL_ACT_TANH);
+    }
   } else if constexpr (op.kind == POL_RING_LOAD) {
     SCopy<A, I> tmp;  // a ring load that is not in the prologue
     s_copy_load<A, I>(c, tmp);
@@ -523,7 +560,7 @@ inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
     if (a.kind != b.kind || a.in_off != b.in_off || a.in_dim != b.in_dim || a.out_buf != b.out_buf || a.out_off != b.out_off ||
         a.out_dim != b.out_dim || a.act != b.act || a.flags != b.flags)
       return false;
-    if ((a.kind == QD_POL_DENSE || a.kind == QD_POL_RING_LOAD || a.kind == QD_POL_RING_PUSH) && a.in_buf != b.in_buf) return false;
+    if ((a.kind == QD_POL_DENSE || a.kind == QD_POL_RING_LOAD || a.kind == QD_POL_RING_PUSH || a.kind == QD_POL_LSTM_CELL) && a.in_buf != b.in_buf) return false;
   }
   return true;
 }
@@ -536,6 +573,8 @@ inline int pol_arch_of(const qd_policy_desc* d, const qd_policy_op* ops) {
   if (pol_matches<ArchRmaFullAdapt>(d, ops)) return 4;
   if (pol_matches<ArchCnnEst>(d, ops)) return 5;
   if (pol_matches<ArchCnnEstHist>(d, ops)) return 6;
+  if (pol_matches<ArchCustomMlp>(d, ops)) return 7;
+  if (pol_matches<ArchLstmEst>(d, ops)) return 8;
   return 0;
 }
 

@@ -391,6 +391,21 @@ def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, p
         bn("_hidden_layers.4", 96)
         fc("_logits.0", 96, 64); fc("_logits.1", 64, 64); fc("_logits.2", 64, num_outputs)
         fc("_value_branch.0", 96, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+    elif family == "CustomMLP":
+        x = num_states + num_params + num_actions
+        bn("_hidden_layers.0", x)
+        for k, (i, o) in enumerate(((x, 256), (256, 128), (128, 128), (128, 96))):
+            fc("_hidden_layers.%d" % (k + 1), i, o)
+        bn("_hidden_layers.5", 96)
+        fc("_logits.0", 96, 64); fc("_logits.1", 64, 64); fc("_logits.2", 64, num_outputs)
+        fc("_value_branch.0", 96, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+    elif family in ("LSTMestimator", "LSTMestimator_estimate"):   # 19-value observation (15 drone + 4 pendulum)
+        fc("_hidden.0", 23, 256); fc("_hidden.1", 256, 128); fc("_logits.0", 128, num_outputs)
+        fc("_value_branch.0", 128, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+        em = "estimation_module."
+        fc(em + "MLP1.0", 34, 32); fc(em + "MLP1.1", 32, 32); fc(em + "MLP2.0", 32, 32); fc(em + "MLP2.1", 32, 4)
+        for nm, shape in (("weight_ih_l0", (128, 32)), ("weight_hh_l0", (128, 32)), ("bias_ih_l0", (128,)), ("bias_hh_l0", (128,))):
+            w[em + "LSTM." + nm] = (rng.normal(size=shape) * (0.17 if len(shape) == 2 else 0.1)).astype(np.float32)
     elif family == "SimpleMLPmodel":
         x = num_states + num_params + num_actions
         for trunk, tail in (("_logits", (64, 64, num_outputs)), ("_value_branch", (128, 128, 1))):
