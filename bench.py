@@ -210,7 +210,7 @@ def main():
     gathers = [par.FragmentGather(f, world) for f in frags] if world > 1 else None
     for f in frags:
         f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
-    state = {"cur": 0, "gathers": 0, "graph_steps": 0, "call_steps": 0}
+    state = {"cur": 0, "gathers": 0, "graph_steps": 0, "call_steps": 0, "use_graph": use_graph}
 
     def run(k_steps, base=0, gather=False):
         t = 0
@@ -222,8 +222,13 @@ def main():
                     w.wait()
                 pending[cur] = None
             f = frags[cur]
-            if use_graph and tt == 0 and k_steps - t >= T:
-                env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
+            if state["use_graph"] and tt == 0 and k_steps - t >= T:
+                try:
+                    env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
+                except Exception as ex:      # a runtime that cannot capture: fall back to per-step calls for the rest of the run
+                    state["use_graph"] = False
+                    print("bench: HIP graph path disabled (%r)" % (ex,), file=sys.stderr)
+                    continue
                 state["graph_steps"] += T
                 t += T
                 tt = T - 1
