@@ -205,12 +205,14 @@ def main():
     # the timed region has no collective; with N > 1 the per-fragment RCCL all-gather that hands trajectories
     # to a central learner is measured right after it, alone and overlapped with stepping, and reported separately.
     pending = [None, None]
-    use_graph = args.config != "config2" and not os.environ.get("QD_BENCH_NO_GRAPH")
+    use_graph = not os.environ.get("QD_BENCH_NO_GRAPH")
     frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
     gathers = [par.FragmentGather(f, world) for f in frags] if world > 1 else None
     for f in frags:
         f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
     state = {"cur": 0, "gathers": 0, "graph_steps": 0, "call_steps": 0, "use_graph": use_graph}
+    # per-step slices of the fragments, made once (tensor indexing costs more than the launch it feeds)
+    views = [[(f.actions[t], (f.obs[t], f.rewards[t], f.truncated[t])) for t in range(T)] for f in frags]
 
     def run(k_steps, base=0, gather=False):
         t = 0
@@ -233,7 +235,8 @@ def main():
                 t += T
                 tt = T - 1
             else:
-                step(f.actions[tt], out=(f.obs[tt], f.rewards[tt], f.truncated[tt]))
+                a_t, out_t = views[cur][tt]
+                step(a_t, out=out_t)
                 state["call_steps"] += 1
                 t += 1
             if tt == T - 1:
@@ -258,7 +261,9 @@ def main():
     # clock ramp: a fresh process finds the GPU in a low power state and a 4 us kernel every 5 us takes tens of ms to pull the
     # shader clock up (measured: the same K steps are 2-12 % slower after 512 untimed steps than after 8192).  These extra
     # untimed steps come before the W warmup steps of the contract and are reported in config.clock_ramp_steps.
-    ramp = max(0, 8192 - W)
+    ramp = (8192 + T - 1) // T * T - W        # >= 8192 - W steps, and the timed region starts on a fragment boundary
+    while ramp < 0:
+        ramp += T
     ramp_s = float(os.environ.get("QD_BENCH_RAMP_S", "0"))
     if ramp_s > 0:
         t_r = time.perf_counter()

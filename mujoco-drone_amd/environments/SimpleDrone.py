@@ -84,6 +84,11 @@ class SimpleDrone:
         o, r, t = out if out is not None else (None, None, None)
         return self._dev.step(actions, o, r, t)
 
+    def step_fragment_tensor(self, actions, obs, reward, terminated):
+        """T steps (actions [T,N,4] on the device) written in place into obs [T,N,6], reward [T,N], terminated [T,N]: the per-step
+        kernels replayed from a HIP graph (qd_step_fragment)"""
+        return self._dev.step_fragment(actions, obs, reward, terminated)
+
     def reset_model(self):
         self._dev.reset(None, want_obs=True)
         return self._dev.obs.cpu().numpy().astype(np.float64).ravel()
