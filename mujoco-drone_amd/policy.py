@@ -9,6 +9,7 @@ Families (eval mode; constructor arguments as in train_PPO.py:39-45):
   "CustomMLP"       models/PPO/MLP/CustomMLP.py:17-98
   "CNNestimator"    models/PPO/CustomLSTM/StateEstimatorLSTM.py:200-283 with use_estimate=False (train_LSTM.py:51-60; obs_dim =
                     num_states = 23); "CNNestimator_estimate": use_estimate=True, TimeCNN over the 32-step history, incremental
+  "CustomLSTM"      models/PPO/CustomLSTM/CustomLSTM.py:14-105 (recurrent actor: nn.LSTM(64, 64) in the action path)
   "LSTMestimator"   models/PPO/CustomLSTM/StateEstimatorLSTM.py:15-147 (obs_dim 19), use_estimate=False; "LSTMestimator_estimate":
                     the nn.LSTM pendulum-state estimator in the loop (h, c and the previous observation kept per env)
   "RMA_full_adapt"  RMA_full with train_adaptation=True, adapt_seq_len=32 (train_RMA.py:39-45): the adaptation CNN over the
@@ -314,7 +315,29 @@ def _lstm_estimator(p, D, ns, npar, na, use_estimate):
     return dict(widths=widths, logits=(P, 0, nl), value=(X, 0))
 
 
-_FAMILIES = {"LSTMestimator": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, False),
+def _custom_lstm(p, D, ns, npar, na):
+    """CustomLSTM (models/PPO/CustomLSTM/CustomLSTM.py:14-105): features = BatchNorm(MLP1(cat(obs, prev_action))) [64],
+    logits = _logits(nn.LSTM(64, 64)(features) + features), value from the features; h and c in one-row rings"""
+    X, P, A, B, S, G = 0, 1, 2, 3, 4, 5
+    w, H = p.w, 64
+    r_h, r_c = p.ring(1, H, 1, np.zeros(H)), p.ring(1, H, 1, np.zeros(H))
+    p.copy_obs(0, D, X, 0); p.copy_prev(na, X, D)
+    p.ring_load(r_h, (S, H)); p.ring_load(r_c, (S, 2 * H))
+    p.fc("MLP1.0", (X, 0), (S, 0), "tanh")
+    p.bn("bn", S, 0)                                                                 # :83 BatchNorm1d over the feature axis
+    Wg = np.concatenate([w["LSTM.weight_ih_l0"], w["LSTM.weight_hh_l0"]], axis=1)
+    p.dense(Wg, w["LSTM.bias_ih_l0"] + w["LSTM.bias_hh_l0"], (S, 0), (G, 0), None)
+    p.lstm_cell((G, 0), (S, H), H)
+    p.ring_push((S, H), r_h); p.ring_push((S, 2 * H), r_c)
+    Wl = w["_logits.0._model.0.weight"]
+    nl = p.dense(np.concatenate([Wl, Wl], axis=1), w["_logits.0._model.0.bias"], (S, 0), (P, 0), None)   # _logits(f + features), f = h'
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (S, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (X, 0), None)
+    return dict(widths=[max(32, D + na), 16, 128, 16, 3 * H, 4 * H], logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"CustomLSTM": _custom_lstm, "LSTMestimator": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, False),
              "LSTMestimator_estimate": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, True),
              "CustomMLP": _custom_mlp, "CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 

@@ -143,6 +143,27 @@ def lstm_estimator(w, obs_seq, action_seq, use_estimate=True):
     return np.stack(logits, 1), np.stack(value, 1), np.stack(est, 1)
 
 
+def custom_lstm(w, obs_seq, action_seq):
+    """CustomLSTM.forward_rnn (CustomLSTM.py:80-87) over whole episodes: features = BatchNorm(MLP1(cat(obs, prev_action))),
+    logits = _logits(LSTM(features) + features), value = _value_branch(features); returns (logits [B,T,8], value [B,T])"""
+    o, a = np.asarray(obs_seq, np.float64), np.asarray(action_seq, np.float64)
+    Bn, Tn, _ = o.shape
+    f64 = lambda k: np.asarray(w[k], np.float64)
+    Wih, Whh, b = f64("LSTM.weight_ih_l0"), f64("LSTM.weight_hh_l0"), f64("LSTM.bias_ih_l0") + f64("LSTM.bias_hh_l0")
+    H = Whh.shape[1]
+    sig = lambda x: 1.0 / (1.0 + np.exp(-x))
+    h, c = np.zeros((Bn, H)), np.zeros((Bn, H))
+    logits, value = [], []
+    for t in range(Tn):
+        a_prev = a[:, t - 1] if t > 0 else np.zeros((Bn, a.shape[2]))
+        feat = _bn(w, "bn", _seq(w, "MLP1", np.concatenate([o[:, t], a_prev], axis=-1), ["tanh"]))
+        g = feat @ Wih.T + h @ Whh.T + b
+        c = sig(g[:, H:2 * H]) * c + sig(g[:, :H]) * np.tanh(g[:, 2 * H:3 * H])
+        h = sig(g[:, 3 * H:]) * np.tanh(c)
+        logits.append(_seq(w, "_logits", h + feat, [None])); value.append(_seq(w, "_value_branch", feat, ["tanh", None])[:, 0])
+    return np.stack(logits, 1), np.stack(value, 1)
+
+
 FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp, "custom_mlp": custom_mlp}
 
 

@@ -249,6 +249,28 @@ def main():
     out["lstm_est_keys"] = np.array(list(sd.keys()))
     for k, v in sd.items():
         out["lstm_est/" + k] = v.numpy()
+    # CustomLSTM (models/PPO/CustomLSTM/CustomLSTM.py:14-105): the LSTM sits in the action path; forward_rnn on explicit sequences
+    from models.PPO.CustomLSTM.CustomLSTM import CustomLSTM
+    torch.manual_seed(19)
+    model = CustomLSTM(obs_space, act_space, 8, {"custom_model_config": {'num_states': 22, 'num_params': 0, 'num_actions': 4}}, "custom_lstm")
+    _randomise(model, gen)
+    with torch.no_grad():
+        for name, prm in model.LSTM.named_parameters():
+            if "bias" in name:
+                prm.copy_(torch.randn(prm.shape, generator=gen) * 0.1)
+    model.eval()
+    o_seq = torch.randn((Bn, Tn, D), generator=gen) * 1.2
+    a_seq = torch.rand((Bn, Tn, 4), generator=gen)
+    a_prev = torch.cat([torch.zeros((Bn, 1, 4)), a_seq[:, :-1]], dim=1)
+    with torch.no_grad():
+        logits, state_out = model.forward_rnn(torch.cat([o_seq, a_prev], dim=-1), [torch.zeros((Bn, 64)), torch.zeros((Bn, 64))], None, False)
+        value = model.value_function()
+    out["custom_lstm_obs_seq"], out["custom_lstm_action_seq"] = o_seq.numpy(), a_seq.numpy()
+    out["custom_lstm_logits"], out["custom_lstm_value"] = logits.numpy(), value.numpy().reshape(Bn, Tn)
+    sd = model.state_dict()
+    out["custom_lstm_keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        out["custom_lstm/" + k] = v.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

@@ -523,3 +523,19 @@ def test_evaluate_trajectory_like_evaluation_py(PG, golden_traj=None):
         np.testing.assert_allclose(actions[k], a[0].cpu().numpy(), atol=2e-5)
         assert abs(rewards[k] - float(rw[0])) < 2e-5
     assert list(e1.reference) == [float(v) for v in traj[-1]]
+
+
+def test_custom_lstm_recurrent_actor_vs_reference_model(PG):
+    """CustomLSTM (the LSTM in the action path): stepped one observation at a time on the device against the reference
+    model's outputs over 24-step episodes"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    w = weights_of(PG, "custom_lstm")
+    pol = DevicePolicy("CustomLSTM", w)
+    assert pol.has_history
+    o, a = PG["custom_lstm_obs_seq"], PG["custom_lstm_action_seq"]
+    pol.reset_state(o.shape[0])
+    for t in range(o.shape[1]):
+        prev = torch.tensor(a[:, t - 1], device="cuda") if t > 0 else None
+        _, logits, value = pol.forward(torch.tensor(o[:, t], device="cuda"), prev, None, counter=t, want_logits=True, want_value=True)
+        np.testing.assert_allclose(logits.cpu().numpy(), PG["custom_lstm_logits"][:, t], atol=3e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(value.cpu().numpy(), PG["custom_lstm_value"][:, t], atol=3e-5)

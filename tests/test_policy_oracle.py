@@ -94,3 +94,11 @@ def test_lstm_estimator_oracle_vs_reference_model(PG):
     np.testing.assert_allclose(est, PG["lstm_est_estimates"], atol=3e-6)
     np.testing.assert_allclose(logits, PG["lstm_est_logits"], atol=3e-6)
     np.testing.assert_allclose(value, PG["lstm_est_value"], atol=3e-6)
+
+
+def test_custom_lstm_oracle_vs_reference_model(PG):
+    """CustomLSTM.forward_rnn: the LSTM in the action path, BatchNorm on the features, 24-step episodes"""
+    from oracle import policy_ref as P
+    logits, value = P.custom_lstm(weights_of(PG, "custom_lstm"), PG["custom_lstm_obs_seq"], PG["custom_lstm_action_seq"])
+    np.testing.assert_allclose(logits, PG["custom_lstm_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["custom_lstm_value"], atol=3e-6)
