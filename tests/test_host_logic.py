@@ -126,3 +126,19 @@ def test_config_translation_without_device(monkeypatch):
         B.BaseDroneEnv(dict(cfg, terminated_fcn=lambda *a: False))
     with pytest.raises(TypeError):
         B.BaseDroneEnv(dict(cfg, reward_fcn=lambda *a: 0.0))
+
+
+def test_trajectory_generators_mirror_reference(golden):
+    """mujoco_drone_amd.evaluation's waypoint generators (host-side configuration arrays) equal the outputs of the reference's
+    gen_*_trajectory functions (evaluation.py:135-152)"""
+    import importlib
+    ev = importlib.import_module("mujoco_drone_amd.evaluation")
+    G = golden
+    _, st = ev.gen_step_trajectory(G["traj_step_args"][0], G["traj_step_args"][1], G["traj_start"], G["traj_end"])
+    _, rp = ev.gen_ramp_trajectory(G["traj_ramp_args"][0], G["traj_ramp_args"][1], G["traj_start"], G["traj_end"])
+    _, ci = ev.gen_circle_trajectory(2.0, 0.5, 1.0, 15.0)
+    np.testing.assert_array_equal(st, G["traj_step"])
+    np.testing.assert_allclose(rp, G["traj_ramp"], atol=1e-13)
+    np.testing.assert_allclose(ci, G["traj_circle"], atol=1e-13)
+    np.testing.assert_array_equal(ev.gen_step_trajectory()[1], G["traj_step_default"])
+    np.testing.assert_allclose(ev.gen_ramp_trajectory()[1], G["traj_ramp_default"], atol=1e-13)
