@@ -194,6 +194,75 @@ struct ArchLstmEst {  // LSTMestimator with the nn.LSTM estimate (StateEstimator
       3, {{1, 15, 1}, {1, 32, 1}, {1, 32, 1}}};
 };
 // (the windowed networks and SimpleMLPmodel / CustomMLP / CNNestimator / LSTMestimator declare no auxiliary slice)
+// the remaining variants the training scripts import; buffers by index (0 X, 1 P, 2 A, 3 B, 4 S, 5 G), see policy.py
+struct ArchRmaSmaller {  // RMA_model_smaller (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {13,
+      {{POL_COPY_OBS, 0, 0, 16, 0, 0, 16, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 0, 16, 4, 0, 0}, {POL_COPY_OBS, 0, 16, 6, 1, 0, 6, 0, 0},
+       {POL_DENSE, 1, 0, 6, 2, 0, 32, TANH, 0}, {POL_DENSE, 2, 0, 32, 0, 20, 8, TANH, 0}, {POL_DENSE, 0, 0, 28, 2, 0, 256, TANH, 0},
+       {POL_DENSE, 2, 0, 256, 3, 0, 128, TANH, 0}, {POL_AFFINE, 3, 0, 128, 3, 0, 128, 0, 0}, {POL_DENSE, 3, 0, 128, 2, 0, 128, TANH, 0},
+       {POL_DENSE, 2, 0, 128, 1, 0, 8, 0, 0}, {POL_DENSE, 3, 0, 128, 2, 0, 128, TANH, SV}, {POL_DENSE, 2, 0, 128, 2, 128, 128, TANH, SV},
+       {POL_DENSE, 2, 128, 128, 0, 0, 1, 0, SV}},
+      4, {32, 16, 256, 128}, 22, 4, 1, 0, 8, 0, 0,
+      0, {}, 0, 20, 8};
+};
+struct ArchRmaSmaller2 {  // RMA_model_smaller2 (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {14,
+      {{POL_COPY_OBS, 0, 0, 16, 0, 0, 16, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 0, 16, 4, 0, 0}, {POL_COPY_OBS, 0, 16, 6, 1, 0, 6, 0, 0},
+       {POL_DENSE, 1, 0, 6, 2, 0, 32, TANH, 0}, {POL_DENSE, 2, 0, 32, 0, 20, 8, TANH, 0}, {POL_DENSE, 0, 0, 28, 2, 0, 512, TANH, 0},
+       {POL_DENSE, 2, 0, 512, 3, 0, 256, TANH, 0}, {POL_AFFINE, 3, 0, 256, 3, 0, 256, 0, 0}, {POL_DENSE, 3, 0, 256, 1, 0, 8, 0, 0},
+       {POL_DENSE, 3, 0, 256, 3, 256, 256, TANH, SV}, {POL_DENSE, 3, 0, 512, 2, 0, 128, TANH, SV}, {POL_DENSE, 2, 0, 128, 2, 256, 128, TANH, SV},
+       {POL_DENSE, 2, 256, 128, 2, 128, 128, TANH, SV}, {POL_DENSE, 2, 0, 256, 0, 0, 1, 0, SV}},
+      4, {32, 16, 512, 512}, 22, 4, 1, 0, 8, 0, 0,
+      0, {}, 0, 20, 8};
+};
+struct ArchCustomLstm {  // CustomLSTM (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {13,
+      {{POL_COPY_OBS, 0, 0, 22, 0, 0, 22, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 0, 22, 4, 0, 0}, {POL_RING_LOAD, 0, 0, 64, 4, 64, 64, 0, 0},
+       {POL_RING_LOAD, 1, 0, 64, 4, 128, 64, 0, 0}, {POL_DENSE, 0, 0, 26, 4, 0, 64, TANH, 0}, {POL_AFFINE, 4, 0, 64, 4, 0, 64, 0, 0},
+       {POL_DENSE, 4, 0, 128, 5, 0, 256, 0, 0}, {POL_LSTM_CELL, 5, 0, 256, 4, 64, 64, 0, 0}, {POL_RING_PUSH, 4, 64, 64, 0, 0, 64, 0, 0},
+       {POL_RING_PUSH, 4, 128, 64, 1, 0, 64, 0, 0}, {POL_DENSE, 4, 0, 128, 1, 0, 8, 0, 0}, {POL_DENSE, 4, 0, 64, 2, 0, 128, TANH, SV},
+       {POL_DENSE, 2, 0, 128, 0, 0, 1, 0, SV}},
+      6, {32, 16, 128, 16, 192, 256}, 22, 4, 1, 0, 8, 0, 0,
+      2, {{1, 64, 1}, {1, 64, 1}}, 0, 0, 0};
+};
+struct ArchLstmBigger {  // CustomLSTMbigger (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {16,
+      {{POL_COPY_OBS, 0, 0, 22, 0, 0, 22, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 0, 22, 4, 0, 0}, {POL_RING_LOAD, 0, 0, 64, 4, 64, 64, 0, 0},
+       {POL_RING_LOAD, 1, 0, 64, 4, 128, 64, 0, 0}, {POL_DENSE, 0, 0, 26, 2, 0, 64, TANH, 0}, {POL_DENSE, 2, 0, 64, 4, 0, 64, TANH, 0},
+       {POL_AFFINE, 4, 0, 64, 4, 0, 64, 0, 0}, {POL_DENSE, 4, 0, 128, 5, 0, 256, 0, 0}, {POL_LSTM_CELL, 5, 0, 256, 4, 64, 64, 0, 0},
+       {POL_RING_PUSH, 4, 64, 64, 0, 0, 64, 0, 0}, {POL_RING_PUSH, 4, 128, 64, 1, 0, 64, 0, 0}, {POL_DENSE, 4, 0, 128, 2, 0, 64, TANH, 0},
+       {POL_DENSE, 2, 0, 64, 1, 0, 8, 0, 0}, {POL_DENSE, 4, 0, 64, 2, 0, 128, TANH, SV}, {POL_DENSE, 2, 0, 128, 2, 128, 128, TANH, SV},
+       {POL_DENSE, 2, 128, 128, 0, 0, 1, 0, SV}},
+      6, {32, 16, 256, 16, 192, 256}, 22, 4, 1, 0, 8, 0, 0,
+      2, {{1, 64, 1}, {1, 64, 1}}, 0, 0, 0};
+};
+struct ArchLstmCommonF {  // CustomLSTMbiggerCommonF (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {16,
+      {{POL_COPY_OBS, 0, 0, 22, 0, 0, 22, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 0, 22, 4, 0, 0}, {POL_RING_LOAD, 0, 0, 64, 4, 64, 64, 0, 0},
+       {POL_RING_LOAD, 1, 0, 64, 4, 128, 64, 0, 0}, {POL_DENSE, 0, 0, 26, 2, 0, 64, TANH, 0}, {POL_DENSE, 2, 0, 64, 4, 0, 64, TANH, 0},
+       {POL_AFFINE, 4, 0, 64, 4, 0, 64, 0, 0}, {POL_DENSE, 4, 0, 128, 5, 0, 256, 0, 0}, {POL_LSTM_CELL, 5, 0, 256, 4, 64, 64, 0, 0},
+       {POL_RING_PUSH, 4, 64, 64, 0, 0, 64, 0, 0}, {POL_RING_PUSH, 4, 128, 64, 1, 0, 64, 0, 0}, {POL_DENSE, 4, 0, 128, 2, 0, 64, TANH, 0},
+       {POL_DENSE, 2, 0, 64, 1, 0, 8, 0, 0}, {POL_DENSE, 4, 0, 128, 2, 0, 128, TANH, SV}, {POL_DENSE, 2, 0, 128, 2, 128, 128, TANH, SV},
+       {POL_DENSE, 2, 128, 128, 0, 0, 1, 0, SV}},
+      6, {32, 16, 256, 16, 192, 256}, 22, 4, 1, 0, 8, 0, 0,
+      2, {{1, 64, 1}, {1, 64, 1}}, 0, 0, 0};
+};
+struct ArchDsnLstm {  // DSN_LSTM_model (mujoco_drone_amd/policy.py; table printed by tools/emit_policy_arch.py)
+  static constexpr SProg prog = {15,
+      {{POL_COPY_OBS, 0, 0, 12, 0, 0, 12, 0, 0}, {POL_COPY_PREV, 0, 0, 4, 4, 0, 4, 0, 0}, {POL_RING_LOAD, 0, 0, 160, 4, 84, 160, 0, 0},
+       {POL_DENSE, 0, 0, 12, 2, 0, 160, TANH, 0}, {POL_DENSE, 2, 0, 160, 3, 0, 160, TANH, 0}, {POL_DENSE, 3, 0, 160, 4, 4, 80, TANH, 0},
+       {POL_AFFINE, 4, 4, 80, 4, 4, 80, 0, 0}, {POL_DENSE, 4, 4, 160, 5, 0, 320, 0, 0}, {POL_LSTM_CELL, 5, 0, 320, 4, 84, 80, 0, 0},
+       {POL_RING_PUSH, 4, 84, 160, 0, 0, 160, 0, 0}, {POL_DENSE, 4, 0, 164, 2, 0, 64, TANH, 0}, {POL_DENSE, 2, 0, 64, 1, 0, 8, 0, 0},
+       {POL_DENSE, 4, 4, 80, 2, 0, 128, TANH, SV}, {POL_DENSE, 2, 0, 128, 2, 128, 128, TANH, SV}, {POL_DENSE, 2, 128, 128, 0, 0, 1, 0, SV}},
+      6, {16, 16, 256, 160, 256, 320}, 22, 4, 1, 0, 8, 0, 0,
+      1, {{1, 160, 1}}, 0, 0, 0};
+};
+
+// every specialisation and the id qd_policy_kernel() reports for it (0 = the generic interpreter, qd_policy.h)
+#define QD_POL_ARCHS(X)                                                                                                  \
+  X(1, ArchRmaFull) X(2, ArchRmaModel) X(3, ArchSimpleMlp) X(4, ArchRmaFullAdapt) X(5, ArchCnnEst) X(6, ArchCnnEstHist) \
+  X(7, ArchCustomMlp) X(8, ArchLstmEst) X(9, ArchRmaSmaller) X(10, ArchRmaSmaller2) X(11, ArchCustomLstm)              \
+  X(12, ArchLstmBigger) X(13, ArchLstmCommonF) X(14, ArchDsnLstm)
 
 // ---- the specialised kernel ----
 struct SCtx {
@@ -567,14 +636,10 @@ inline bool pol_matches(const qd_policy_desc* d, const qd_policy_op* ops) {
 inline int pol_arch_of(const qd_policy_desc* d, const qd_policy_op* ops) {
   const char* e = getenv("QD_POLICY_GENERIC");  // testing: force the interpreter
   if (e && atoi(e)) return 0;
-  if (pol_matches<ArchRmaFull>(d, ops)) return 1;
-  if (pol_matches<ArchRmaModel>(d, ops)) return 2;
-  if (pol_matches<ArchSimpleMlp>(d, ops)) return 3;
-  if (pol_matches<ArchRmaFullAdapt>(d, ops)) return 4;
-  if (pol_matches<ArchCnnEst>(d, ops)) return 5;
-  if (pol_matches<ArchCnnEstHist>(d, ops)) return 6;
-  if (pol_matches<ArchCustomMlp>(d, ops)) return 7;
-  if (pol_matches<ArchLstmEst>(d, ops)) return 8;
+#define QD_POL_MATCH(ID, ARCH) \
+  if (pol_matches<ARCH>(d, ops)) return ID;
+  QD_POL_ARCHS(QD_POL_MATCH)
+#undef QD_POL_MATCH
   return 0;
 }
 

@@ -89,9 +89,9 @@ class _Program:
         self.ops.append(L.QdPolicyOp(L.POL_LSTM_CELL, gates[0], gates[1], 4 * hidden, hc[0], hc[1], hidden, 0, self.flags, 0, 0, 0))
 
     def bn(self, prefix, buf, off):
-        """eval-mode BatchNorm1d `prefix` in place"""
-        g, b = self.w[prefix + ".weight"].astype(np.float64), self.w[prefix + ".bias"].astype(np.float64)
-        m, v = self.w[prefix + ".running_mean"].astype(np.float64), self.w[prefix + ".running_var"].astype(np.float64)
+        """eval-mode BatchNorm1d `prefix` (or the concatenation of several, given as a tuple of prefixes) in place"""
+        cat = lambda key: np.concatenate([self.w[q + key].astype(np.float64) for q in ((prefix,) if isinstance(prefix, str) else prefix)])
+        g, b, m, v = cat(".weight"), cat(".bias"), cat(".running_mean"), cat(".running_var")
         scale = g / np.sqrt(v + BN_EPS)
         self.ops.append(L.QdPolicyOp(L.POL_AFFINE, buf, off, len(g), buf, off, len(g), 0, self.flags, 0, self._put(scale),
                                      self._put(b - m * scale)))
@@ -337,7 +337,130 @@ def _custom_lstm(p, D, ns, npar, na):
     return dict(widths=[max(32, D + na), 16, 128, 16, 3 * H, 4 * H], logits=(P, 0, nl), value=(X, 0))
 
 
-_FAMILIES = {"CustomLSTM": _custom_lstm, "LSTMestimator": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, False),
+def _rma_model_small(p, D, ns, npar, na, wide):
+    """RMA_model_smaller (RMA_model.py:311-347; wide=False) and RMA_model_smaller2 (the definition Python keeps, :398-437; wide=True):
+    RMA_model.forward (:262-292) over a 256-128 / 512-256 trunk.  ResBlock(x) = hidden(x) + x (:350-357) costs no extra op: the
+    block's output is written right behind its input and the layer after it reads both halves through [W | W]."""
+    X, P, A, B = 0, 1, 2, 3
+    w = p.w
+    p.copy_obs(0, ns, X, 0); p.copy_prev(na, X, ns); p.copy_obs(ns, npar, P, 0)
+    p.fc("param_encoder.0", (P, 0), (A, 0), "tanh")
+    z = p.fc("param_encoder.1", (A, 0), (X, ns + na), "tanh")
+    p.fc("_hidden_layers.0", (X, 0), (A, 0), "tanh")
+    f = p.fc("_hidden_layers.1", (A, 0), (B, 0), "tanh")
+    p.bn("_hidden_layers.2", B, 0)
+    if not wide:
+        p.fc("_logits.0", (B, 0), (A, 0), "tanh")
+        nl = p.fc("_logits.1", (A, 0), (P, 0), None)
+        p.flags = L.POL_VALUE_ONLY
+        p.fc("_value_branch.0", (B, 0), (A, 0), "tanh")
+        p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+        p.fc("_value_branch.2", (A, 128), (X, 0), None)
+        widths = [max(32, ns + na + z), 16, 256, 128]
+    else:
+        nl = p.fc("_logits.0", (B, 0), (P, 0), None)
+        p.flags = L.POL_VALUE_ONLY
+        p.fc("_value_branch.0.hidden.0", (B, 0), (B, f), "tanh")                        # ResBlock(256, 1): [features | hidden(features)]
+        W1 = w["_value_branch.1._model.0.weight"]
+        v = p.dense(np.concatenate([W1, W1], axis=1), w["_value_branch.1._model.0.bias"], (B, 0), (A, 0), "tanh")
+        p.fc("_value_branch.2.hidden.0", (A, 0), (A, 2 * v), "tanh")                    # ResBlock(128, 2): [v | hidden(v)]
+        p.fc("_value_branch.2.hidden.1", (A, 2 * v), (A, v), "tanh")
+        W3 = w["_value_branch.3._model.0.weight"]
+        p.dense(np.concatenate([W3, W3], axis=1), w["_value_branch.3._model.0.bias"], (A, 0), (X, 0), None)
+        widths = [max(32, ns + na + z), 16, 512, 2 * f]
+    return dict(widths=widths, logits=(P, 0, nl), value=(X, 0), aux=(X, ns + na, z))
+
+
+def _custom_lstm_bigger(p, D, ns, npar, na, common_f):
+    """CustomLSTMbigger (CustomLSTM.py:107-201) / CustomLSTMbiggerCommonF (:204-299): y = BatchNorm(MLP1(cat(obs, prev_action))) over two
+    layers, logits = _logits(nn.LSTM(64, 64)(y) + y); the value head reads y (bigger) or LSTM(y) + y (CommonF)"""
+    X, P, A, B, S, G = 0, 1, 2, 3, 4, 5
+    w, H = p.w, 64
+    r_h, r_c = p.ring(1, H, 1, np.zeros(H)), p.ring(1, H, 1, np.zeros(H))
+    p.copy_obs(0, D, X, 0); p.copy_prev(na, X, D)
+    p.ring_load(r_h, (S, H)); p.ring_load(r_c, (S, 2 * H))
+    p.fc("MLP1.0", (X, 0), (A, 0), "tanh")
+    p.fc("MLP1.1", (A, 0), (S, 0), "tanh")
+    p.bn("bn", S, 0)
+    Wg = np.concatenate([w["LSTM.weight_ih_l0"], w["LSTM.weight_hh_l0"]], axis=1)
+    p.dense(Wg, w["LSTM.bias_ih_l0"] + w["LSTM.bias_hh_l0"], (S, 0), (G, 0), None)
+    p.lstm_cell((G, 0), (S, H), H)
+    p.ring_push((S, H), r_h); p.ring_push((S, 2 * H), r_c)
+    Wl = w["_logits.0._model.0.weight"]
+    p.dense(np.concatenate([Wl, Wl], axis=1), w["_logits.0._model.0.bias"], (S, 0), (A, 0), "tanh")      # _logits(f + y), f = h'
+    nl = p.fc("_logits.1", (A, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    if common_f:
+        Wv = w["_value_branch.0._model.0.weight"]
+        p.dense(np.concatenate([Wv, Wv], axis=1), w["_value_branch.0._model.0.bias"], (S, 0), (A, 0), "tanh")
+    else:
+        p.fc("_value_branch.0", (S, 0), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[max(32, D + na), 16, 256, 16, 3 * H, 4 * H], logits=(P, 0, nl), value=(X, 0))
+
+
+def _block_diag(mats):
+    rows, cols = sum(m.shape[0] for m in mats), sum(m.shape[1] for m in mats)
+    out, r, c = np.zeros((rows, cols), dtype=np.float64), 0, 0
+    for m in mats:
+        out[r:r + m.shape[0], c:c + m.shape[1]] = m
+        r, c = r + m.shape[0], c + m.shape[1]
+    return out
+
+
+def _dsn_lstm(p, D, ns, npar, na):
+    """DSN_LSTM_model (models/PPO/DSN_LSTM/DSN_LSTM_model.py:20-160): obs[:12] viewed [4, 3] and split into x / y / z columns, one
+    MLP + BatchNorm + nn.LSTM per axis (32 / 32 / 16 wide), mixer on cat(LSTM outputs + features, prev_actions), value on the features.
+    The three per-axis networks are independent, so they run here as ONE network with block-structured weights: layer 1 picks its
+    axis' columns out of obs[:12], layers 2-3 are block-diagonal, and the three LSTMs are one 80-wide LSTM whose W_ih / W_hh are
+    block-diagonal per gate (the cell update is elementwise).  h | c travel in one 160-wide ring."""
+    X, P, A, B, S, G = 0, 1, 2, 3, 4, 5
+    w = p.w
+    axes, Hs = ("x", "y", "z"), (32, 32, 16)
+    H = sum(Hs)
+    f64 = lambda k: np.asarray(w[k], np.float64)
+    r_hc = p.ring(1, 2 * H, 1, np.zeros(2 * H))
+    p.copy_obs(0, 12, X, 0); p.copy_prev(na, S, 0)
+    p.ring_load(r_hc, (S, na + H))
+    W1 = []
+    for k, ax in enumerate(axes):                                                    # :121-124 xyz_obs[..., k] = obs[k::3][:4]
+        Wk = f64(ax + "_hidden.0._model.0.weight")
+        E = np.zeros((Wk.shape[0], 12)); E[:, k::3] = Wk
+        W1.append(E)
+    cat_b = lambda i: np.concatenate([f64("%s_hidden.%d._model.0.bias" % (ax, i)) for ax in axes])
+    p.dense(np.concatenate(W1, axis=0), cat_b(0), (X, 0), (A, 0), "tanh")
+    p.dense(_block_diag([f64(ax + "_hidden.1._model.0.weight") for ax in axes]), cat_b(1), (A, 0), (B, 0), "tanh")
+    p.dense(_block_diag([f64(ax + "_hidden.2._model.0.weight") for ax in axes]), cat_b(2), (B, 0), (S, na), "tanh")
+    p.bn(tuple("bn_" + ax for ax in axes), S, na)                                    # features = cat(x_f, y_f, z_f)
+    Wg, bg = np.zeros((4 * H, 2 * H)), np.zeros(4 * H)
+    for gate in range(4):                                                            # i, f, g, o
+        o = 0
+        for ax, h in zip(axes, Hs):
+            rows = slice(gate * H + o, gate * H + o + h)
+            Wg[rows, o:o + h] = f64("LSTM_%s.weight_ih_l0" % ax)[gate * h:(gate + 1) * h]
+            Wg[rows, H + o:H + o + h] = f64("LSTM_%s.weight_hh_l0" % ax)[gate * h:(gate + 1) * h]
+            bg[rows] = (f64("LSTM_%s.bias_ih_l0" % ax) + f64("LSTM_%s.bias_hh_l0" % ax))[gate * h:(gate + 1) * h]
+            o += h
+    p.dense(Wg, bg, (S, na), (G, 0), None)
+    p.lstm_cell((G, 0), (S, na + H), H)
+    p.ring_push((S, na + H), r_hc)
+    Wm = f64("mixer.0._model.0.weight")                                              # :137-138 cat(f + features, actions)
+    p.dense(np.concatenate([Wm[:, H:H + na], Wm[:, :H], Wm[:, :H]], axis=1), f64("mixer.0._model.0.bias"), (S, 0), (A, 0), "tanh")
+    nl = p.fc("mixer.1", (A, 0), (P, 0), None)
+    p.flags = L.POL_VALUE_ONLY
+    p.fc("_value_branch.0", (S, na), (A, 0), "tanh")
+    p.fc("_value_branch.1", (A, 0), (A, 128), "tanh")
+    p.fc("_value_branch.2", (A, 128), (X, 0), None)
+    return dict(widths=[16, 16, 256, 160, na + 3 * H + 12, 4 * H], logits=(P, 0, nl), value=(X, 0))
+
+
+_FAMILIES = {"CustomLSTM": _custom_lstm,
+             "CustomLSTMbigger": lambda p, D, ns, npar, na: _custom_lstm_bigger(p, D, ns, npar, na, False),
+             "CustomLSTMbiggerCommonF": lambda p, D, ns, npar, na: _custom_lstm_bigger(p, D, ns, npar, na, True),
+             "DSN_LSTM_model": _dsn_lstm,
+             "RMA_model_smaller": lambda p, D, ns, npar, na: _rma_model_small(p, D, ns, npar, na, False),
+             "RMA_model_smaller2": lambda p, D, ns, npar, na: _rma_model_small(p, D, ns, npar, na, True), "LSTMestimator": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, False),
              "LSTMestimator_estimate": lambda p, D, ns, npar, na: _lstm_estimator(p, D, ns, npar, na, True),
              "CustomMLP": _custom_mlp, "CNNestimator": _cnn_estimator, "CNNestimator_estimate": _cnn_estimator_estimate, "RMA_full": _rma_full, "RMA_model": _rma_model, "SimpleMLPmodel": _simple_mlp, "RMA_full_adapt": _rma_full_adapt}
 
@@ -379,6 +502,12 @@ def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, p
         w[name + ".bias"] = (0.1 * rng.normal(size=n)).astype(np.float32)
         w[name + ".running_mean"] = (0.2 * rng.normal(size=n)).astype(np.float32)
         w[name + ".running_var"] = rng.uniform(0.25, 1.75, n).astype(np.float32)
+
+    def lstm(name, hidden):   # nn.LSTM(hidden, hidden): uniform(-1/sqrt(H), 1/sqrt(H)) like torch
+        k = 1.0 / np.sqrt(hidden)
+        for nm, shape in (("weight_ih_l0", (4 * hidden, hidden)), ("weight_hh_l0", (4 * hidden, hidden)), ("bias_ih_l0", (4 * hidden,)),
+                          ("bias_hh_l0", (4 * hidden,))):
+            w["%s.%s" % (name, nm)] = rng.uniform(-k, k, shape).astype(np.float32)
 
     h_in = num_states + num_actions + param_embed_dim
     if family in ("CNNestimator", "CNNestimator_estimate"):   # num_states = 23 (LocalFrameFullStateEnv)
@@ -429,6 +558,34 @@ def random_weights(family, seed=0, num_states=16, num_params=6, num_actions=4, p
         fc(em + "MLP1.0", 34, 32); fc(em + "MLP1.1", 32, 32); fc(em + "MLP2.0", 32, 32); fc(em + "MLP2.1", 32, 4)
         for nm, shape in (("weight_ih_l0", (128, 32)), ("weight_hh_l0", (128, 32)), ("bias_ih_l0", (128,)), ("bias_hh_l0", (128,))):
             w[em + "LSTM." + nm] = (rng.normal(size=shape) * (0.17 if len(shape) == 2 else 0.1)).astype(np.float32)
+    elif family in ("RMA_model_smaller", "RMA_model_smaller2"):
+        wide = family.endswith("2")
+        a, b = (512, 256) if wide else (256, 128)
+        fc("param_encoder.0", num_params, 32); fc("param_encoder.1", 32, param_embed_dim)
+        fc("_hidden_layers.0", h_in, a); fc("_hidden_layers.1", a, b); bn("_hidden_layers.2", b)
+        if wide:
+            fc("_logits.0", b, num_outputs)
+            fc("_value_branch.0.hidden.0", 256, 256); fc("_value_branch.1", 256, 128)
+            fc("_value_branch.2.hidden.0", 128, 128); fc("_value_branch.2.hidden.1", 128, 128); fc("_value_branch.3", 128, 1)
+        else:
+            fc("_logits.0", 128, 128); fc("_logits.1", 128, num_outputs)
+            fc("_value_branch.0", 128, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+    elif family in ("CustomLSTM", "CustomLSTMbigger", "CustomLSTMbiggerCommonF"):   # input = cat(obs, prev_actions)
+        x = num_states + num_params + num_actions
+        if family == "CustomLSTM":
+            fc("MLP1.0", x, 64); fc("_logits.0", 64, num_outputs); fc("_value_branch.0", 64, 128); fc("_value_branch.1", 128, 1)
+        else:
+            fc("MLP1.0", x, 64); fc("MLP1.1", 64, 64); fc("_logits.0", 64, 64); fc("_logits.1", 64, num_outputs)
+            fc("_value_branch.0", 64, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
+        bn("bn", 64)
+        lstm("LSTM", 64)
+    elif family == "DSN_LSTM_model":
+        for ax, (a, b) in (("x", (64, 32)), ("y", (64, 32)), ("z", (32, 16))):
+            fc(ax + "_hidden.0", 4, a); fc(ax + "_hidden.1", a, a); fc(ax + "_hidden.2", a, b)
+            bn("bn_" + ax, b)
+            lstm("LSTM_" + ax, b)
+        fc("mixer.0", 84, 64); fc("mixer.1", 64, num_outputs)
+        fc("_value_branch.0", 80, 128); fc("_value_branch.1", 128, 128); fc("_value_branch.2", 128, 1)
     elif family == "SimpleMLPmodel":
         x = num_states + num_params + num_actions
         for trunk, tail in (("_logits", (64, 64, num_outputs)), ("_value_branch", (128, 128, 1))):

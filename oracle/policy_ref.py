@@ -164,6 +164,78 @@ def custom_lstm(w, obs_seq, action_seq):
     return np.stack(logits, 1), np.stack(value, 1)
 
 
+def rma_model_smaller(w, obs, prev_actions, num_states=16, num_params=6):
+    """RMA_model_smaller (RMA_model.py:311-347): RMA_model.forward (:262-292) over RMA_full-sized layers, the encoder ending in tanh;
+    returns (logits, value, z)"""
+    obs, prev = np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)
+    z = _seq(w, "param_encoder", obs[:, num_states:num_states + num_params], ["tanh", "tanh"])
+    feat = _seq(w, "_hidden_layers", np.concatenate([obs[:, :num_states], prev, z], axis=-1), ["tanh", "tanh", "bn"])
+    return _seq(w, "_logits", feat, ["tanh", None]), _seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0], z
+
+
+def rma_model_smaller2(w, obs, prev_actions, num_states=16, num_params=6):
+    """RMA_model_smaller2 (the definition Python keeps, RMA_model.py:398-437): 512 -> 256 trunk, a single linear logits layer, value
+    head ResBlock(256, 1) -> 128 -> ResBlock(128, 2) -> 1 with ResBlock(x) = hidden(x) + x (:350-357); returns (logits, value, z)"""
+    obs, prev = np.asarray(obs, np.float64), np.asarray(prev_actions, np.float64)
+    z = _seq(w, "param_encoder", obs[:, num_states:num_states + num_params], ["tanh", "tanh"])
+    feat = _seq(w, "_hidden_layers", np.concatenate([obs[:, :num_states], prev, z], axis=-1), ["tanh", "tanh", "bn"])
+    v = _seq(w, "_value_branch.0.hidden", feat, ["tanh"]) + feat
+    v = _fc(w, "_value_branch.1", v, "tanh")
+    v = _seq(w, "_value_branch.2.hidden", v, ["tanh", "tanh"]) + v
+    return _seq(w, "_logits", feat, [None]), _fc(w, "_value_branch.3", v, None)[:, 0], z
+
+
+def _lstm_step(w, prefix, x, h, c):
+    """one nn.LSTM step, gate order i, f, g, o"""
+    f64 = lambda k: np.asarray(w[k], np.float64)
+    H = h.shape[1]
+    g = x @ f64(prefix + ".weight_ih_l0").T + h @ f64(prefix + ".weight_hh_l0").T + f64(prefix + ".bias_ih_l0") + f64(prefix + ".bias_hh_l0")
+    sig = lambda v: 1.0 / (1.0 + np.exp(-v))
+    c = sig(g[:, H:2 * H]) * c + sig(g[:, :H]) * np.tanh(g[:, 2 * H:3 * H])
+    return sig(g[:, 3 * H:]) * np.tanh(c), c
+
+
+def custom_lstm_bigger(w, obs_seq, action_seq, common_f=False):
+    """CustomLSTMbigger.forward_rnn (CustomLSTM.py:171-178): y = BatchNorm(MLP1(cat(obs, prev_action))) (two layers), logits =
+    _logits(LSTM(y) + y), value = _value_branch(y); CustomLSTMbiggerCommonF (:268-276, common_f=True): the value head reads
+    LSTM(y) + y too; returns (logits [B,T,8], value [B,T])"""
+    o, a = np.asarray(obs_seq, np.float64), np.asarray(action_seq, np.float64)
+    Bn, Tn, _ = o.shape
+    H = np.asarray(w["LSTM.weight_hh_l0"]).shape[1]
+    h, c = np.zeros((Bn, H)), np.zeros((Bn, H))
+    logits, value = [], []
+    for t in range(Tn):
+        a_prev = a[:, t - 1] if t > 0 else np.zeros((Bn, a.shape[2]))
+        y = _bn(w, "bn", _seq(w, "MLP1", np.concatenate([o[:, t], a_prev], axis=-1), ["tanh", "tanh"]))
+        h, c = _lstm_step(w, "LSTM", y, h, c)
+        logits.append(_seq(w, "_logits", h + y, ["tanh", None]))
+        value.append(_seq(w, "_value_branch", h + y if common_f else y, ["tanh", "tanh", None])[:, 0])
+    return np.stack(logits, 1), np.stack(value, 1)
+
+
+def dsn_lstm(w, obs_seq, action_seq):
+    """DSN_LSTM_model.forward_rnn (DSN_LSTM_model.py:119-141): obs[:12] viewed [4, 3] and split into its x / y / z columns, one
+    MLP + BatchNorm + nn.LSTM per axis (32, 32, 16 wide), mixer on cat(LSTM outputs + features, prev_actions), value head on the
+    features; returns (logits [B,T,8], value [B,T])"""
+    o, a = np.asarray(obs_seq, np.float64), np.asarray(action_seq, np.float64)
+    Bn, Tn, _ = o.shape
+    axes = (("x", 32), ("y", 32), ("z", 16))
+    st = {ax: (np.zeros((Bn, H)), np.zeros((Bn, H))) for ax, H in axes}
+    logits, value = [], []
+    for t in range(Tn):
+        a_prev = a[:, t - 1] if t > 0 else np.zeros((Bn, a.shape[2]))
+        xyz = o[:, t, :12].reshape(Bn, 4, 3)
+        feats, outs = [], []
+        for k, (ax, H) in enumerate(axes):
+            f = _bn(w, "bn_" + ax, _seq(w, ax + "_hidden", xyz[:, :, k], ["tanh", "tanh", "tanh"]))
+            st[ax] = _lstm_step(w, "LSTM_" + ax, f, *st[ax])
+            feats.append(f); outs.append(st[ax][0])
+        feat = np.concatenate(feats, axis=-1)
+        logits.append(_seq(w, "mixer", np.concatenate([np.concatenate(outs, axis=-1) + feat, a_prev], axis=-1), ["tanh", None]))
+        value.append(_seq(w, "_value_branch", feat, ["tanh", "tanh", None])[:, 0])
+    return np.stack(logits, 1), np.stack(value, 1)
+
+
 FAMILIES = {"rma_full": rma_full, "rma_model": rma_model, "simple_mlp": simple_mlp, "custom_mlp": custom_mlp}
 
 

@@ -5,7 +5,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mujoco_drone_amd.policy import DevicePolicy, random_weights
 FAMS = [("RMA_full", 22), ("RMA_model", 22), ("SimpleMLPmodel", 22), ("CustomMLP", 22), ("RMA_full_adapt", 22), ("CNNestimator", 23),
-        ("CNNestimator_estimate", 23), ("LSTMestimator_estimate", 19)]
+        ("CNNestimator_estimate", 23), ("LSTMestimator_estimate", 19), ("RMA_model_smaller", 22), ("RMA_model_smaller2", 22),
+        ("CustomLSTM", 22), ("CustomLSTMbigger", 22), ("CustomLSTMbiggerCommonF", 22), ("DSN_LSTM_model", 22)]
 n = 4096
 for fam, D in FAMS:
     kw = dict(obs_dim=D, num_states=D if D != 22 else 16)

@@ -271,6 +271,69 @@ def main():
     out["custom_lstm_keys"] = np.array(list(sd.keys()))
     for k, v in sd.items():
         out["custom_lstm/" + k] = v.numpy()
+    # the remaining variants the training scripts import (train_PPO.py:7-10, evaluation.py:7): RMA_model_smaller and
+    # RMA_model_smaller2 (the second definition, RMA_model.py:398-437, is the one Python keeps; residual blocks in the value
+    # head), same inputs as rma_model
+    from models.PPO.RMA.RMA_model import RMA_model_smaller, RMA_model_smaller2
+    for tag, cls, seed in (("rma_smaller", RMA_model_smaller, 23), ("rma_smaller2", RMA_model_smaller2, 29)):
+        torch.manual_seed(seed)
+        model = cls(obs_space, act_space, 8, {"custom_model_config": cc}, tag)
+        _randomise(model, gen)
+        model.eval()
+        with torch.no_grad():
+            logits, _ = model.forward({"obs": obs, "prev_actions": prev, "is_training": False}, [], None)
+            value = model.value_function()
+        out[tag + "_logits"], out[tag + "_value"], out[tag + "_z"] = logits.numpy(), value.numpy(), model.z.numpy()
+        sd = model.state_dict()
+        out[tag + "_keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out[tag + "/" + k] = v.numpy()
+    # CustomLSTMbigger / CustomLSTMbiggerCommonF (CustomLSTM.py:107-299) and DSN_LSTM_model (DSN_LSTM_model.py:20-160):
+    # forward_rnn on explicit 24-step episodes from zero state
+    from models.PPO.CustomLSTM.CustomLSTM import CustomLSTMbigger, CustomLSTMbiggerCommonF
+    from models.PPO.DSN_LSTM.DSN_LSTM_model import DSN_LSTM_model
+    for tag, cls, seed in (("lstm_bigger", CustomLSTMbigger, 31), ("lstm_common_f", CustomLSTMbiggerCommonF, 37)):
+        torch.manual_seed(seed)
+        model = cls(obs_space, act_space, 8, {"custom_model_config": {'num_states': 22, 'num_params': 0, 'num_actions': 4}}, tag)
+        _randomise(model, gen)
+        with torch.no_grad():
+            for name, prm in model.LSTM.named_parameters():
+                if "bias" in name:
+                    prm.copy_(torch.randn(prm.shape, generator=gen) * 0.1)
+        model.eval()
+        o_seq = torch.randn((Bn, Tn, D), generator=gen) * 1.2
+        a_seq = torch.rand((Bn, Tn, 4), generator=gen)
+        a_prev = torch.cat([torch.zeros((Bn, 1, 4)), a_seq[:, :-1]], dim=1)
+        with torch.no_grad():
+            logits, state_out = model.forward_rnn(torch.cat([o_seq, a_prev], dim=-1), [torch.zeros((Bn, 64)), torch.zeros((Bn, 64))], None, False)
+            value = model.value_function()
+        out[tag + "_obs_seq"], out[tag + "_action_seq"] = o_seq.numpy(), a_seq.numpy()
+        out[tag + "_logits"], out[tag + "_value"] = logits.numpy(), value.numpy().reshape(Bn, Tn)
+        sd = model.state_dict()
+        out[tag + "_keys"] = np.array(list(sd.keys()))
+        for k, v in sd.items():
+            out[tag + "/" + k] = v.numpy()
+    torch.manual_seed(41)
+    model = DSN_LSTM_model(obs_space, act_space, 8, {"custom_model_config": cc}, "dsn_lstm")
+    _randomise(model, gen)
+    with torch.no_grad():
+        for lstm in (model.LSTM_x, model.LSTM_y, model.LSTM_z):
+            for name, prm in lstm.named_parameters():
+                if "bias" in name:
+                    prm.copy_(torch.randn(prm.shape, generator=gen) * 0.1)
+    model.eval()
+    o_seq = torch.randn((Bn, Tn, D), generator=gen) * 1.2
+    a_seq = torch.rand((Bn, Tn, 4), generator=gen)
+    a_prev = torch.cat([torch.zeros((Bn, 1, 4)), a_seq[:, :-1]], dim=1)
+    with torch.no_grad():
+        logits, state_out = model.forward_rnn(o_seq, a_prev, [torch.zeros((Bn, k)) for k in (32, 32, 32, 32, 16, 16)], None, False)
+        value = model.value_function()
+    out["dsn_lstm_obs_seq"], out["dsn_lstm_action_seq"] = o_seq.numpy(), a_seq.numpy()
+    out["dsn_lstm_logits"], out["dsn_lstm_value"] = logits.numpy(), value.numpy().reshape(Bn, Tn)
+    sd = model.state_dict()
+    out["dsn_lstm_keys"] = np.array(list(sd.keys()))
+    for k, v in sd.items():
+        out["dsn_lstm/" + k] = v.numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

@@ -539,3 +539,43 @@ def test_custom_lstm_recurrent_actor_vs_reference_model(PG):
         _, logits, value = pol.forward(torch.tensor(o[:, t], device="cuda"), prev, None, counter=t, want_logits=True, want_value=True)
         np.testing.assert_allclose(logits.cpu().numpy(), PG["custom_lstm_logits"][:, t], atol=3e-5, err_msg="t=%d" % t)
         np.testing.assert_allclose(value.cpu().numpy(), PG["custom_lstm_value"][:, t], atol=3e-5)
+
+
+@pytest.mark.parametrize("tag,family", [("rma_smaller", "RMA_model_smaller"), ("rma_smaller2", "RMA_model_smaller2")])
+def test_smaller_rma_variants_vs_reference_models(PG, tag, family, kernel):
+    """RMA_model_smaller / RMA_model_smaller2 (residual blocks in the value head folded into the following layer's weights)"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    pol = DevicePolicy(family, weights_of(PG, tag))
+    assert (pol.kernel > 0) == (kernel == "specialised")
+    obs, prev = torch.tensor(PG["obs"], device="cuda"), torch.tensor(PG["prev_actions"], device="cuda")
+    act, logits, value = pol.forward(obs, prev, want_logits=True, want_value=True)
+    np.testing.assert_allclose(logits.cpu().numpy(), PG[tag + "_logits"], atol=2e-5)
+    np.testing.assert_allclose(value.cpu().numpy(), PG[tag + "_value"], atol=2e-5)
+    np.testing.assert_allclose(pol.embedding(obs, prev).cpu().numpy(), PG[tag + "_z"], atol=1e-5)
+    np.testing.assert_array_equal(pol.forward(obs, prev).cpu().numpy(), act.cpu().numpy())
+
+
+@pytest.mark.parametrize("tag,family", [("lstm_bigger", "CustomLSTMbigger"), ("lstm_common_f", "CustomLSTMbiggerCommonF"),
+                                        ("dsn_lstm", "DSN_LSTM_model")])
+def test_recurrent_variants_vs_reference_models(PG, tag, family, kernel):
+    """CustomLSTMbigger / CustomLSTMbiggerCommonF / DSN_LSTM_model (its three per-axis LSTMs run as one block-diagonal LSTM):
+    stepped one observation at a time against the reference models' outputs over 24-step episodes; then a second episode on
+    half of the envs (prev_truncated) restarts from the zero state"""
+    from mujoco_drone_amd.policy import DevicePolicy
+    pol = DevicePolicy(family, weights_of(PG, tag))
+    assert pol.has_history and (pol.kernel > 0) == (kernel == "specialised")
+    o, a = PG[tag + "_obs_seq"], PG[tag + "_action_seq"]
+    n, T = o.shape[0], o.shape[1]
+    pol.reset_state(n)
+    for t in range(T):
+        prev = torch.tensor(a[:, t - 1], device="cuda") if t > 0 else None
+        _, logits, value = pol.forward(torch.tensor(o[:, t], device="cuda"), prev, None, counter=t, want_logits=True, want_value=True)
+        np.testing.assert_allclose(logits.cpu().numpy(), PG[tag + "_logits"][:, t], atol=3e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(value.cpu().numpy(), PG[tag + "_value"][:, t], atol=3e-5)
+    fresh = np.zeros(n, dtype=np.uint8)
+    fresh[::2] = 1
+    _, logits, _ = pol.forward(torch.tensor(o[:, 0], device="cuda"), torch.tensor(a[:, T - 1], device="cuda"),
+                               torch.tensor(fresh, device="cuda"), counter=T, want_logits=True, want_value=True)
+    got = logits.cpu().numpy()
+    np.testing.assert_allclose(got[::2], PG[tag + "_logits"][::2, 0], atol=3e-5)
+    assert np.abs(got[1::2] - PG[tag + "_logits"][1::2, 0]).max() > 1e-3        # the others carry their state on

@@ -102,3 +102,41 @@ def test_custom_lstm_oracle_vs_reference_model(PG):
     logits, value = P.custom_lstm(weights_of(PG, "custom_lstm"), PG["custom_lstm_obs_seq"], PG["custom_lstm_action_seq"])
     np.testing.assert_allclose(logits, PG["custom_lstm_logits"], atol=3e-6)
     np.testing.assert_allclose(value, PG["custom_lstm_value"], atol=3e-6)
+
+
+def test_smaller_rma_variants_oracle_vs_reference_models(PG):
+    """RMA_model_smaller and RMA_model_smaller2 (residual blocks in the value head), the variants train_PPO.py / evaluation.py import"""
+    from oracle import policy_ref as P
+    for tag, fn in (("rma_smaller", P.rma_model_smaller), ("rma_smaller2", P.rma_model_smaller2)):
+        logits, value, z = fn(weights_of(PG, tag), PG["obs"], PG["prev_actions"])
+        np.testing.assert_allclose(logits, PG[tag + "_logits"], atol=3e-6, err_msg=tag)
+        np.testing.assert_allclose(value, PG[tag + "_value"], atol=3e-6, err_msg=tag)
+        np.testing.assert_allclose(z, PG[tag + "_z"], atol=3e-6, err_msg=tag)
+
+
+def test_recurrent_variants_oracle_vs_reference_models(PG):
+    """CustomLSTMbigger, CustomLSTMbiggerCommonF and DSN_LSTM_model: forward_rnn over 24-step episodes from the zero state"""
+    from oracle import policy_ref as P
+    for tag, common in (("lstm_bigger", False), ("lstm_common_f", True)):
+        logits, value = P.custom_lstm_bigger(weights_of(PG, tag), PG[tag + "_obs_seq"], PG[tag + "_action_seq"], common)
+        np.testing.assert_allclose(logits, PG[tag + "_logits"], atol=3e-6, err_msg=tag)
+        np.testing.assert_allclose(value, PG[tag + "_value"], atol=3e-6, err_msg=tag)
+    logits, value = P.dsn_lstm(weights_of(PG, "dsn_lstm"), PG["dsn_lstm_obs_seq"], PG["dsn_lstm_action_seq"])
+    np.testing.assert_allclose(logits, PG["dsn_lstm_logits"], atol=3e-6)
+    np.testing.assert_allclose(value, PG["dsn_lstm_value"], atol=3e-6)
+
+
+@pytest.mark.parametrize("tag,family", [("rma_adapt", "RMA_full_adapt"), ("cnn_est_ff", "CNNestimator"), ("cnn_est_hist", "CNNestimator_estimate"),
+                                        ("lstm_est", "LSTMestimator_estimate"), ("custom_lstm", "CustomLSTM"), ("rma_smaller", "RMA_model_smaller"),
+                                        ("rma_smaller2", "RMA_model_smaller2"), ("lstm_bigger", "CustomLSTMbigger"),
+                                        ("lstm_common_f", "CustomLSTMbiggerCommonF"), ("dsn_lstm", "DSN_LSTM_model")])
+def test_every_family_program_passes_host_validation(PG, tag, family):
+    """each remaining family's layer program is accepted by the library's host-side validation (qd_policy_packed_bytes)"""
+    import ctypes as C
+    from mujoco_drone_amd import _lib as L
+    from mujoco_drone_amd.policy import compile_program
+    dims = {"cnn_est_ff": dict(obs_dim=23, num_states=23), "cnn_est_hist": dict(obs_dim=23, num_states=23),
+            "lstm_est": dict(obs_dim=19, num_states=19)}.get(tag, {})
+    d, ops, blob = compile_program(family, weights_of(PG, tag), **dims)
+    assert L.lib().qd_policy_packed_bytes(C.byref(d), ops) > 0, L.last_error()
+    assert d.n_logits == 8 and d.n_ops <= 32
