@@ -872,3 +872,33 @@ def test_step_fragment_graph_replay_equals_steps(qd):
         np.testing.assert_allclose(obs2[t].cpu().numpy(), o.cpu().numpy(), atol=1e-6)
     for a, b in zip(e1._dev.get_state(), e2._dev.get_state()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6)
+
+
+@pytest.mark.parametrize("n", [1, 63, 65, 4097, 65535, 65536, 98303, 98304, 131073])
+def test_ragged_and_threshold_batch_sizes(qd, n):
+    """batch sizes that are not multiples of the wavefront / workgroup, and the sizes at which the library switches launch
+    variants (reset-sampler workgroups below 65536 envs, 256-thread workgroups from 98304): env i's observations, rewards and
+    truncations, through resets and re-sampling, are bit-identical to the same env in a 64-env batch -- within one launch
+    variant: the 256-thread instantiation of k_step is compiled separately and its fused multiply-adds fall differently, 1 ulp
+    per step (tests/diag_variant_diff.py), so from 98304 envs the comparison is to 2e-6 over a 7-step episode; the last env of
+    the ragged tail is finite and stepped exactly as often as the first"""
+    L, T = qd._lib, 24
+    m = min(n, 64)
+    mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, start=1, random_params=1, auto_reset=1, max_steps=7, seed=9))
+    big, small = mk(n), mk(m)
+    big.reset(); small.reset()
+    g = torch.Generator(device="cuda").manual_seed(n)
+    for t in range(T):
+        a = torch.rand((n, 4), generator=g, device="cuda")
+        ob, rb, tb = big.step(a)
+        os_, rs, ts = small.step(a[:m].contiguous())
+        if n < 98304:
+            assert torch.equal(ob[:m], os_) and torch.equal(rb[:m], rs) and torch.equal(tb[:m], ts), "t=%d" % t
+        else:
+            assert torch.allclose(ob[:m], os_, rtol=0, atol=2e-6) and torch.allclose(rb[:m], rs, rtol=0, atol=2e-6) and torch.equal(tb[:m], ts)
+        if t % 7 == 6:
+            assert bool(tb.all())                       # every env, the tail included, hit max_steps together
+    q, v, a_, s, k = big.get_state()
+    assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(ob).all()
+    assert int(k[0]) == int(k[-1]) == T % 7
+    assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(n, device=q.device), atol=1e-5)
