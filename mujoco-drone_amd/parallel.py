@@ -41,42 +41,59 @@ def shard_bounds(total_envs, rank, world):
 
 
 class FragmentBuffers:
-    """Per-rank rollout fragment [T, N, ...] the step kernel writes into directly (no staging copy)."""
+    """Per-rank rollout fragment [T, N, ...] the step kernel writes into directly (no staging copy).  The four tensors are
+    views of ONE contiguous slab (each section 256-byte aligned), so a fragment travels as a single collective."""
 
-    def __init__(self, T, n, obs_dim, device):
+    ALIGN = 256
+
+    def __init__(self, T, n, obs_dim, device, slab=None):
         self.T, self.n, self.D = T, n, obs_dim
-        self.obs = torch.empty((T, n, obs_dim), dtype=torch.float32, device=device)
-        self.actions = torch.empty((T, n, 4), dtype=torch.float32, device=device)
-        self.rewards = torch.empty((T, n), dtype=torch.float32, device=device)
-        self.truncated = torch.empty((T, n), dtype=torch.uint8, device=device)
+        shapes = (("obs", (T, n, obs_dim), torch.float32), ("actions", (T, n, 4), torch.float32),
+                  ("rewards", (T, n), torch.float32), ("truncated", (T, n), torch.uint8))
+        self.sections, off = {}, 0
+        for name, shape, dtype in shapes:
+            nbytes = int(torch.tensor([], dtype=dtype).element_size())
+            for x in shape:
+                nbytes *= x
+            self.sections[name] = (off, nbytes, shape, dtype)
+            off = (off + nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.slab_bytes = off
+        self.slab = torch.empty((off,), dtype=torch.uint8, device=device) if slab is None else slab
+        assert self.slab.numel() == off and self.slab.dtype == torch.uint8
+        for name, (o, nbytes, shape, dtype) in self.sections.items():
+            setattr(self, name, self.slab[o:o + nbytes].view(dtype).view(shape))
 
     def tensors(self):
         return {"obs": self.obs, "actions": self.actions, "rewards": self.rewards, "truncated": self.truncated}
 
     def nbytes(self):
+        """payload bytes (without the alignment padding between sections)"""
         return sum(t.numel() * t.element_size() for t in self.tensors().values())
 
 
 class FragmentGather:
-    """All-gather of one fragment per call.  Output layout: [world, T, N, ...] (rank-major), i.e. the
-    learner sees world*N envs.  Output buffers are allocated once and reused."""
+    """All-gather of one fragment per call: ONE collective over the fragment's slab (457 MB per rank at T=1024, N=4096,
+    D=22 -- large messages are what xGMI's point-to-point links want).  Output layout: [world, T, N, ...] (rank-major),
+    i.e. the learner sees world*N envs.  Output buffers are allocated once and reused."""
 
     def __init__(self, frag: FragmentBuffers, world):
         self.world = world
-        self.out = {k: torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-                    for k, t in frag.tensors().items()}
+        self.out_slab = torch.empty((world, frag.slab_bytes), dtype=torch.uint8, device=frag.slab.device)
+        self.parts = [FragmentBuffers(frag.T, frag.n, frag.D, frag.slab.device, slab=self.out_slab[r]) for r in range(world)]
+        self.out = {}
+        for name, (o, nbytes, shape, dtype) in frag.sections.items():
+            # strided [world, ...] view over the gathered slabs (no copy): row r = rank r's section (slab sizes and section
+            # offsets are multiples of 256 bytes, so the reinterpretation is exact)
+            esz = self.parts[0].tensors()[name].element_size()
+            flat = self.out_slab.view(dtype)                                        # [world, slab_bytes / esz]
+            self.out[name] = flat[:, o // esz:(o + nbytes) // esz].view((world,) + tuple(shape))
 
     def __call__(self, frag: FragmentBuffers, async_op=False):
         if self.world == 1 or not dist.is_initialized():
-            for k, t in frag.tensors().items():
-                self.out[k][0].copy_(t)
+            self.out_slab[0].copy_(frag.slab)
             return self.out, []
-        works = []
-        for k, t in frag.tensors().items():
-            # concatenated form [world*T, N, ...] of the same buffer: accepted by both RCCL and gloo
-            flat = self.out[k].view((self.world * t.shape[0],) + tuple(t.shape[1:]))
-            works.append(dist.all_gather_into_tensor(flat, t, async_op=async_op))
-        return self.out, [w for w in works if w is not None]
+        work = dist.all_gather_into_tensor(self.out_slab.view(-1), frag.slab, async_op=async_op)
+        return self.out, [work] if work is not None else []
 
     def learner_view(self):
         """[T, world*N, ...] views for the learner (env axis = rank-major concatenation)"""
