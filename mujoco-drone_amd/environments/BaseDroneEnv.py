@@ -301,6 +301,31 @@ class BaseDroneEnv(_VectorEnvBase):
         self._cache().pop('states', None)
         return self.states
 
+    def state_vector(self):
+        """mujoco_vecenv.py:352-354: concatenated qpos and qvel of the whole model"""
+        qpos, qvel = self._flat_state()[:2]
+        return np.concatenate([qpos, qvel])
+
+    def generate_drone_params(self):
+        """BaseDroneEnv.py:180-216.  The reference only draws here and builds the model from the result later
+        (reset_model(regen=True), :298-310); on the device the draw and the model derivation are one kernel, so the
+        parameters returned here are already the ones the next step uses."""
+        self._dev.randomize_params()
+        self._invalidate()
+        return self.drone_params
+
+    def sample_state(self):
+        """BaseDroneEnv.py:218-257: ONE drone's (qpos, qvel) from the configured start distribution, without touching the
+        batch.  Drawn on the device by a one-env twin of this configuration (its own Philox key), like every reset."""
+        if getattr(self, '_sampler', None) is None:
+            cfg = self._make_cfg()
+            cfg.num_envs, cfg.random_params, cfg.per_env_reference, cfg.ref_mode = 1, 0, 0, 0
+            cfg.seed = int(cfg.seed) + 0x5A17
+            self._sampler = DeviceEnv(cfg, self.device)
+        self._sampler.reset(None)
+        qpos, qvel = self._sampler.get_state()[:2]
+        return qpos[0].cpu().numpy().astype(np.float64), qvel[0].cpu().numpy().astype(np.float64)
+
     def _get_obs(self):
         """list of N observation vectors (float64) for the current `states` snapshot"""
         if self._obs_host is None:

@@ -465,6 +465,20 @@ def test_vector_env_surface(qd):
     assert qpos.shape == (72,) and qvel.shape == (64,)
     env.set_state(qpos, qvel)
     np.testing.assert_allclose(env.data.qpos, qpos, atol=1e-6)
+    # the reference's host-callable helpers: state_vector (mujoco_vecenv.py:352-354), sample_state (one drone's draw from the
+    # start distribution, BaseDroneEnv.py:218-257; the batch is untouched), generate_drone_params (:180-216)
+    sv = env.state_vector()
+    assert sv.shape == (72 + 64,) and np.allclose(sv[:72], env.data.qpos)
+    q1, v1 = env.sample_state()
+    q2, v2 = env.sample_state()
+    assert q1.shape == (9,) and v1.shape == (8,) and not np.allclose(q1, q2)
+    assert abs(np.linalg.norm(q1[3:7]) - 1) < 1e-6
+    assert np.linalg.norm(q1[:3] - np.array(cfg['start_pos'][:3])) <= env.max_pos_offset + 1e-6
+    assert np.all(np.abs(v1[:3]) <= 2 * env.vel_variance + 1e-6)
+    np.testing.assert_allclose(env.data.qpos, qpos, atol=1e-6)
+    before = env.drone_params
+    after = env.generate_drone_params()
+    assert len(after) == 8 and after[0] != before[0] and abs(after[0]['mass'] - env.mass_interval[0]) <= env.mass_interval[1] + 1e-9
 
 
 def test_simple_drone_surface(qd, orc):
