@@ -14,7 +14,10 @@
 namespace qd {
 
 constexpr uint32_t STREAM_POLICY = 3u;
-constexpr int POL_TILE = 16, POL_THREADS = 256;  // envs per workgroup (the MFMA M tile), threads per workgroup
+#ifndef QD_POL_THREADS
+#define QD_POL_THREADS 256
+#endif
+constexpr int POL_TILE = 16, POL_THREADS = QD_POL_THREADS;  // envs per workgroup (the MFMA M tile), threads per workgroup
 constexpr int POL_SCRATCH = 64;  // floats reserved behind the activation buffers for the per-env log-prob reduction
 
 struct PolSample {
