@@ -400,6 +400,25 @@ def main():
                         e3._dev.rollout_pid(256)
                     torch.cuda.synchronize()
                     extras["pid_closed_loop_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
+                # what the reference logs about a train batch (custom_logging.py:9-31, training.py:16-22), over the fragment the
+                # timed steps just wrote: per-column min / max / mean / var of obs and actions, episode returns / lengths
+                from mujoco_drone_amd.custom_logging import BatchStatistics, EpisodeStatistics
+                bs, es = BatchStatistics(), EpisodeStatistics(n, device)
+                f0 = frags[0]
+                for name, fn, nbytes in (("obs", lambda: bs.column_stats_tensor(f0.obs), f0.obs.numel() * 4),
+                                         ("actions", lambda: bs.column_stats_tensor(f0.actions), f0.actions.numel() * 4),
+                                         ("episodes", lambda: es.update_tensor(f0.rewards, f0.truncated), f0.rewards.numel() * 5)):
+                    for _ in range(3):
+                        fn()
+                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    ev0.record()
+                    for _ in range(20):
+                        fn()
+                    ev1.record()
+                    torch.cuda.synchronize()
+                    us = ev0.elapsed_time(ev1) * 1000.0 / 20
+                    extras["fragment_%s_stats_us" % name] = us
+                    extras["fragment_%s_stats_GBps" % name] = nbytes / (us * 1e-6) / 1e9
                 if args.config == "config3":
                     # the reference's actor (RMA_full, train_PPO.py:39-45, random-init weights) inside the loop:
                     # policy forward (f32 MFMA) -> env step, 2 launches per step enqueued by one C call, nothing leaves the GPU

@@ -309,6 +309,25 @@ int qd_eval_truncated(int ns, const float* states, const int32_t* num_steps, con
 /* transformation.py:5-29 on n rows */
 int qd_transform(int which, const float* in, float* out, int n, void* stream);
 
+/* ---- train-batch statistics (extension of the data path: what the reference logs about the trajectories) ----
+ * MyCallbacks.on_learn_on_batch (custom_logging.py:9-31) takes train_batch['obs'] and ['actions'] to the host and logs
+ * np.min / np.max / np.mean / np.var of every column.  qd_column_stats computes the same four numbers per column of a
+ * row-major float32 device matrix [rows, cols] (a rollout fragment's obs [T*N, D] or actions [T*N, 4]) in one streaming
+ * pass: out (device, 4*cols doubles) = min[cols] | max[cols] | mean[cols] | var[cols] (population variance, ddof 0 as
+ * np.var; NaNs propagate as in numpy).  Sums are carried in float64 in a fixed order: deterministic, and at least as
+ * accurate as the float32 numpy calls of the reference.  cols <= 64; rows >= 1. */
+size_t qd_column_stats_workspace_bytes(int cols);
+int qd_column_stats(const float* x, int64_t rows, int cols, double* out, void* workspace, size_t workspace_bytes, void* stream);
+/* training.py:16-22 reads RLlib's episode_reward_mean, episode_len_mean and sum(episode_reward) / sum(episode_lengths).
+ * qd_episode_stats derives them from a fragment's reward [T, N] / truncated [T, N]: an episode ends at the step whose
+ * truncated flag is set (its reward counts, BaseDroneEnv.py:276-284).  carry (device, 2*N doubles: return and length of
+ * every env's running episode; zero it before the first fragment) links consecutive fragments.
+ * out (device, 12 doubles) = episodes ended, sum of returns, sum of lengths, sum of squared returns, min / max return,
+ * min / max length, mean return, mean length, sum return / sum length, population std of the returns (NaN if none ended). */
+size_t qd_episode_stats_workspace_bytes(int num_envs);
+int qd_episode_stats(const float* reward, const uint8_t* truncated, int T, int num_envs, double* carry, double* out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

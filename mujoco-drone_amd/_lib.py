@@ -118,6 +118,10 @@ SIGNATURES = {
     "qd_eval_reward": (_I, [_I, _I, _VP, _VP, _VP, _D4, C.c_double, _VP, _I, _VP]),
     "qd_eval_truncated": (_I, [_I, _VP, _VP, _D4, C.c_double, _I, _VP, _I, _VP]),
     "qd_transform": (_I, [_I, _VP, _VP, _I, _VP]),
+    "qd_column_stats_workspace_bytes": (C.c_size_t, [_I]),
+    "qd_column_stats": (_I, [_VP, _I64, _I, _VP, _VP, C.c_size_t, _VP]),
+    "qd_episode_stats_workspace_bytes": (C.c_size_t, [_I]),
+    "qd_episode_stats": (_I, [_VP, _VP, _I, _I, _VP, _VP, _VP, C.c_size_t, _VP]),
 }
 
 _lib = None

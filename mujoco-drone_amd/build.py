@@ -12,7 +12,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB = os.environ.get("QD_LIB") or os.path.join(PKG_DIR, "libqd.so")  # QD_LIB: diagnostic builds only
 SOURCES = ["qd_kernels.hip"]
-HEADERS = ["qd_math.h", "qd_model.h", "qd_dynamics.h", "qd_obsrew.h", "qd_rng.h", "qd_pid.h", "qd_policy.h", "qd_policy_dist.h", "qd_policy_static.h", "qd_policy_host.inc", os.path.join("..", "..", "include", "qd.h")]
+HEADERS = ["qd_math.h", "qd_model.h", "qd_dynamics.h", "qd_obsrew.h", "qd_rng.h", "qd_pid.h", "qd_stats.h", "qd_policy.h", "qd_policy_dist.h", "qd_policy_static.h", "qd_policy_host.inc", os.path.join("..", "..", "include", "qd.h")]
 ARCH = "gfx950"
 
 

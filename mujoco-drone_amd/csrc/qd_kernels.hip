@@ -33,6 +33,7 @@
 #include "qd_policy.h"
 #include "qd_policy_static.h"
 #include "qd_rng.h"
+#include "qd_stats.h"
 
 namespace qd {
 
@@ -1492,6 +1493,83 @@ int qd_transform(int which, const float* in, float* out, int n, void* stream) {
   if (n == 0) return QD_OK;
   if (!in || !out) return fail(QD_ERR_INVALID, "null array argument");
   QD_LAUNCH(k_transform, dim3(blocks64(n)), dim3(64), 0, S(stream), which, in, out, n);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+// ---- what the reference logs about a train batch (custom_logging.py:9-31, training.py:16-22), computed where the fragments lie ----
+size_t qd_column_stats_workspace_bytes(int cols) {
+  if (cols < 1 || cols > qd::STAT_MAX_COLS) return 0;
+  return (size_t)qd::STAT_GROUPS * cols * 4 * sizeof(double);
+}
+
+int qd_column_stats(const float* x, int64_t rows, int cols, double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (cols < 1 || cols > qd::STAT_MAX_COLS) return fail(QD_ERR_UNSUPPORTED, "column statistics support 1..%d columns, got %d", qd::STAT_MAX_COLS, cols);
+  if (rows < 1) return fail(QD_ERR_INVALID, "column statistics of an empty batch are undefined (numpy raises / warns)");
+  if (!x || !out || !workspace) return fail(QD_ERR_INVALID, "null array argument");
+  if (workspace_bytes < qd_column_stats_workspace_bytes(cols) || (reinterpret_cast<uintptr_t>(workspace) & 7))
+    return fail(QD_ERR_ARENA, "workspace too small (qd_column_stats_workspace_bytes) or not 8-byte aligned");
+  if (reinterpret_cast<uintptr_t>(x) & 3) return fail(QD_ERR_INVALID, "matrix not 4-byte aligned");
+  // the pass reads 16-byte units; the floats before the first boundary and after the last whole unit go to the final kernel
+  const long long total = (long long)rows * cols;
+  int head = (int)(((16 - (reinterpret_cast<uintptr_t>(x) & 15)) & 15) / 4);
+  if (head > total) head = (int)total;
+  const long long units = (total - head) / 4;
+  const long long span = (long long)qd::stat_period(cols) * qd::STAT_UNROLL;
+  long long groups = (units + span - 1) / span;
+  if (groups < 1) groups = 1;
+  if (groups > qd::STAT_GROUPS) groups = qd::STAT_GROUPS;
+  double* part = static_cast<double*>(workspace);
+  QD_LAUNCH(qd::k_column_stats, dim3((unsigned)groups), dim3(qd::STAT_THREADS), 0, S(stream), reinterpret_cast<const qd::stat_f4*>(x + head), units, cols,
+            head, part);
+  QD_LAUNCH_CHECK();
+  QD_LAUNCH(qd::k_column_stats_final, dim3((cols + qd::STAT_FINAL_COLS - 1) / qd::STAT_FINAL_COLS), dim3(qd::STAT_FINAL_THREADS), 0, S(stream), part,
+            (int)groups, cols, (long long)rows, x, head, units, out);
+  QD_LAUNCH_CHECK();
+  return QD_OK;
+}
+
+// workspace: [segment summaries: returns S*N*2 doubles | lengths S*N*2 ints | partials (S+1)*G*8 doubles], sized for the most segments
+static void epi_layout(int num_envs, int S, size_t* ret_off, size_t* len_off, size_t* part_off, size_t* total) {
+  const size_t G = (size_t)(num_envs + qd::STAT_THREADS - 1) / qd::STAT_THREADS;
+  *ret_off = 0;
+  *len_off = (size_t)S * num_envs * 2 * sizeof(double);
+  *part_off = (*len_off + (size_t)S * num_envs * 2 * sizeof(int) + 15) / 16 * 16;
+  *total = *part_off + (size_t)(S + 1) * G * qd::EPI_FIELDS * sizeof(double);
+}
+
+size_t qd_episode_stats_workspace_bytes(int num_envs) {
+  if (num_envs < 1) return 0;
+  size_t a, b, c, total;
+  epi_layout(num_envs, qd::EPI_MAX_SEGMENTS, &a, &b, &c, &total);
+  return total;
+}
+
+int qd_episode_stats(const float* reward, const uint8_t* truncated, int T, int num_envs, double* carry, double* out, void* workspace,
+                     size_t workspace_bytes, void* stream) {
+  if (T < 0 || num_envs < 1) return fail(QD_ERR_INVALID, "bad fragment shape [%d, %d]", T, num_envs);
+  if (!reward || !truncated || !carry || !out || !workspace) return fail(QD_ERR_INVALID, "null array argument");
+  if (workspace_bytes < qd_episode_stats_workspace_bytes(num_envs) || (reinterpret_cast<uintptr_t>(workspace) & 15))
+    return fail(QD_ERR_ARENA, "workspace too small (qd_episode_stats_workspace_bytes) or not 16-byte aligned");
+  const int G = (num_envs + qd::STAT_THREADS - 1) / qd::STAT_THREADS;
+  // short walks: as many segments as the workspace is sized for, none shorter than 8 steps
+  int nseg = qd::EPI_MAX_SEGMENTS;
+  if (nseg > T / qd::EPI_MIN_SEGMENT) nseg = T / qd::EPI_MIN_SEGMENT;
+  if (nseg < 1) nseg = 1;
+  const int L = T > 0 ? (T + nseg - 1) / nseg : 1;
+  nseg = T > 0 ? (T + L - 1) / L : 1;
+  size_t ret_off, len_off, part_off, total;
+  epi_layout(num_envs, nseg, &ret_off, &len_off, &part_off, &total);
+  char* ws = static_cast<char*>(workspace);
+  double* seg_ret = reinterpret_cast<double*>(ws + ret_off);
+  int* seg_len = reinterpret_cast<int*>(ws + len_off);
+  double* part = reinterpret_cast<double*>(ws + part_off);
+  QD_LAUNCH(qd::k_episode_segments, dim3(G, nseg), dim3(qd::STAT_THREADS), 0, S(stream), reward, truncated, T, num_envs, L, seg_ret, seg_len, part);
+  QD_LAUNCH_CHECK();
+  QD_LAUNCH(qd::k_episode_stitch, dim3(G), dim3(qd::STAT_THREADS), 0, S(stream), seg_ret, seg_len, nseg, num_envs, carry, part,
+            part + (size_t)nseg * G * qd::EPI_FIELDS);
+  QD_LAUNCH_CHECK();
+  QD_LAUNCH(qd::k_episode_stats_final, dim3(1), dim3(qd::STAT_THREADS), 0, S(stream), part + (size_t)nseg * G * qd::EPI_FIELDS, G, out);
   QD_LAUNCH_CHECK();
   return QD_OK;
 }
