@@ -228,6 +228,9 @@ enum { QD_POL_DENSE = 0, QD_POL_AFFINE = 1, QD_POL_COPY_OBS = 2, QD_POL_COPY_PRE
        QD_POL_LSTM_CELL = 6 };
 enum { QD_ACT_NONE = 0, QD_ACT_TANH = 1, QD_ACT_RELU = 2 };
 enum { QD_POL_VALUE_ONLY = 1 };
+/* action distributions of distributions.py on the network's 2 * act_dim outputs */
+enum { QD_DIST_BETA = 0,              /* MyBetaDist (:6-38): what every training script configures */
+       QD_DIST_SQUASHED_GAUSSIAN = 1  /* MySquashedGaussian (:41-119): mean | log_std, sigmoid squashing to [0, 1] */ };
 typedef struct qd_policy qd_policy;
 typedef struct qd_policy_op {
   int32_t kind, in_buf, in_off, in_dim, out_buf, out_off, out_dim, act;
@@ -252,7 +255,7 @@ typedef struct qd_policy_desc {
   qd_policy_ring ring[4];
   int32_t aux_buf, aux_off, aux_dim; /* an intermediate slice callers may read back (qd_policy_aux), e.g. the parameter
                                         embedding z of the RMA networks (policy.model.z, rollout.py:83); aux_dim 0 = none */
-  int32_t reserved1;
+  int32_t dist;                      /* QD_DIST_*: the action distribution on the logits */
 } qd_policy_desc;
 size_t qd_policy_packed_bytes(const qd_policy_desc* desc, const qd_policy_op* ops);
 int qd_policy_create(const qd_policy_desc* desc, const qd_policy_op* ops, const float* weights_host, size_t n_weights,

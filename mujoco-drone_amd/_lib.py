@@ -65,12 +65,13 @@ class QdPolicyDesc(C.Structure):
     _fields_ = [("n_ops", C.c_int32), ("n_bufs", C.c_int32), ("buf_width", C.c_int32 * 8), ("obs_dim", C.c_int32),
                 ("act_dim", C.c_int32), ("logits_buf", C.c_int32), ("logits_off", C.c_int32), ("n_logits", C.c_int32),
                 ("value_buf", C.c_int32), ("value_off", C.c_int32), ("n_rings", C.c_int32), ("ring", QdPolicyRing * 4),
-                ("aux_buf", C.c_int32), ("aux_off", C.c_int32), ("aux_dim", C.c_int32), ("reserved1", C.c_int32)]
+                ("aux_buf", C.c_int32), ("aux_off", C.c_int32), ("aux_dim", C.c_int32), ("dist", C.c_int32)]
 
 
 POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH, POL_LSTM_CELL = 0, 1, 2, 3, 4, 5, 6
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 POL_VALUE_ONLY = 1
+DIST_BETA, DIST_SQUASHED_GAUSSIAN = 0, 1
 
 # every symbol include/qd.h declares: (restype, argtypes)
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64

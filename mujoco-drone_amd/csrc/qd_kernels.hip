@@ -685,7 +685,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
     PolSample st = smp;
     st.counter = smp.counter + (unsigned int)t;
     pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
-                logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile);
+                logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
     __syncthreads();
     // ---- env step: wave 0, one env per lane ----
     if (wave == 0) {

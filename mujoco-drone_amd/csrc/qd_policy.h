@@ -53,6 +53,7 @@ struct PolArgs {
   int logits_lds, ld_logits, n_logits;   // LDS float offset of env row 0's logits, row stride
   int value_lds, ld_value;               // value_lds < 0: the program has no value head
   int aux_lds, ld_aux, n_aux;            // auxiliary slice read back by qd_policy_aux (n_aux 0: none)
+  int dist;                              // POL_DIST_*: which distribution of distributions.py reads the logits
   long long weights_off;      // float offset of the packed weights in the blob
   // per-env history rings (see qd_policy_ring in include/qd.h)
   int n_rings, state_floats;                     // floats of history per env
@@ -317,7 +318,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
       const int r = k / p.n_aux, c = k - r * p.n_aux;
       if (env0 + r < n_envs) aux[(size_t)(env0 + r) * p.n_aux + c] = lds[p.aux_lds + r * p.ld_aux + c];
     }
-  pol_outputs(lds + p.logits_lds, p.ld_logits, p.n_logits, p.act_dim, env0, n_envs, tid, lds + p.act_floats - POL_SCRATCH, smp, actions, logp, logits);
+  pol_outputs(lds + p.logits_lds, p.ld_logits, p.n_logits, p.act_dim, env0, n_envs, tid, lds + p.act_floats - POL_SCRATCH, smp, actions, logp, logits, nullptr, p.dist);
   POL_STAMP(2 + p.n_ops);
 }
 

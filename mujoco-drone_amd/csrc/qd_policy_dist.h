@@ -1,4 +1,5 @@
-// qd_policy_dist.h -- the output stage shared by both policy kernels: MyBetaDist (distributions.py:6-38) on the logits.
+// qd_policy_dist.h -- the output stage shared by the policy kernels: the action distributions of distributions.py on the logits.
+// MyBetaDist (distributions.py:6-38), what every training script configures:
 //   inputs  = softplus(clamp(logits, -50, 50)) + 1, first half alpha (concentration1), second half beta (:12-17)
 //   deterministic_sample = alpha / (alpha + beta)                                                     (:24-26)
 //   sample               = Beta(alpha, beta) draw (TorchBeta.sample -> torch.distributions.Beta.sample, no squashing)
@@ -7,6 +8,13 @@
 // Philox4x32-10 stream keyed by the caller's seed (as for resets, qd_rng.h), so a rollout is reproducible whatever the
 // scheduling.  Beta(a, b) = Ga / (Ga + Gb) with Marsaglia-Tsang gamma variates; both shapes are >= 1 by construction
 // (softplus + 1), so the shape-boost step for a < 1 is never needed.
+// MySquashedGaussian (distributions.py:41-119), the alternative the scripts import: logits = mean | log_std,
+//   std = exp(clamp(log_std, -5, 5));  _squash = sigmoid (clamped to [0, 1]);  deterministic_sample = sigmoid(mean)   (:54-66, :103-106)
+//   sample  = sigmoid(mean + std * N(0, 1))                                                                         (:68-71)
+//   logp(x) = sum_d clamp(log N(u_d; mean_d, std_d), -100, 100) - sum_d log(1 - tanh(u_d)^2 + 1e-4),
+//             u = atanh(clamp(2 x - 1, -1 + 1e-4, 1 - 1e-4))                                                        (:73-85, :108-112)
+//   QUIRK reproduced: the class squashes with a sigmoid but un-squashes with atanh(2 x - 1) = z / 2, so the log-probability of
+//   its own sample is evaluated at half the pre-squash value.
 #pragma once
 
 #include "qd_rng.h"
@@ -14,6 +22,7 @@
 namespace qd {
 
 constexpr uint32_t STREAM_POLICY = 3u;
+constexpr int POL_DIST_BETA = 0, POL_DIST_SQUASHED_GAUSSIAN = 1;  // = QD_DIST_* of include/qd.h
 #ifndef QD_POL_THREADS
 #define QD_POL_THREADS 256
 #endif
@@ -60,9 +69,17 @@ __device__ __forceinline__ float pol_gamma(float a, const PolSample& s, uint32_t
 // logits (LDS rows lgt[r * ldl + c]) -> actions / logp / logits in global memory for the workgroup's POL_TILE envs.
 // `scratch` = POL_SCRATCH floats of LDS nobody else uses; every thread of the workgroup must call this (it has a barrier
 // when logp is requested).
+// one N(0, 1) variate per (env, step counter, action dimension): Box-Muller on the policy stream
+__device__ __forceinline__ float pol_normal(const PolSample& s, uint32_t env, uint32_t sub) {
+  uint32_t w[4];
+  philox4x32_10(env, s.counter, sub * 16u, STREAM_POLICY, (uint32_t)s.seed, (uint32_t)(s.seed >> 32), w);
+  const float u1 = u32_to_unit(w[0]), u2 = u32_to_unit(w[1]);
+  return __builtin_amdgcn_sqrtf(-1.38629436111989061883f * __builtin_amdgcn_logf(u1)) * __builtin_amdgcn_cosf(u2);
+}
+
 __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, int AD, int env0, int n_envs, int tid, float* scratch,
                                             const PolSample& smp, float* __restrict__ actions, float* __restrict__ logp,
-                                            float* __restrict__ logits, float* act_lds = nullptr) {
+                                            float* __restrict__ logits, float* act_lds = nullptr, int dist = POL_DIST_BETA) {
   if (logits)
     for (int k = tid; k < POL_TILE * NL; k += POL_THREADS) {
       const int r = k / NL, c = k - r * NL;
@@ -72,21 +89,34 @@ __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, i
   if (actions || logp || act_lds) {
     for (int k = tid; k < POL_TILE * H; k += POL_THREADS) {
       const int r = k / H, c = k - r * H;
-      const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + c], -50.f, 50.f);
-      const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
-      float x;
-      if (smp.explore) {
-        const float ga = pol_gamma(al, smp, (uint32_t)(env0 + r), 2u * c), gb = pol_gamma(be, smp, (uint32_t)(env0 + r), 2u * c + 1u);
-        x = ga * __builtin_amdgcn_rcpf(ga + gb);
+      float x, lp = 0.f;
+      if (dist == POL_DIST_SQUASHED_GAUSSIAN) {  // uniform over the launch
+        const float mean = lgt[r * ldl + c], ls = qclamp(lgt[r * ldl + H + c], -5.f, 5.f), sd = __expf(ls);
+        const float z = smp.explore ? fmaf(sd, pol_normal(smp, (uint32_t)(env0 + r), (uint32_t)c), mean) : mean;
+        x = qclamp(__builtin_amdgcn_rcpf(1.0f + __expf(-z)), 0.f, 1.f);
+        if (logp) {
+          const float th = qclamp(2.0f * x - 1.0f, -1.0f + 1e-4f, 1.0f - 1e-4f);
+          const float u = 0.5f * __logf((1.0f + th) / (1.0f - th));  // atanh
+          const float q = (u - mean) / sd;
+          lp = qclamp(-0.5f * q * q - ls - 0.91893853320467274f, -100.f, 100.f) - __logf(1.0f - th * th + 1e-4f);
+        }
       } else {
-        x = al * __builtin_amdgcn_rcpf(al + be);
+        const float la = qclamp(lgt[r * ldl + c], -50.f, 50.f), lb = qclamp(lgt[r * ldl + H + c], -50.f, 50.f);
+        const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
+        if (smp.explore) {
+          const float ga = pol_gamma(al, smp, (uint32_t)(env0 + r), 2u * c), gb = pol_gamma(be, smp, (uint32_t)(env0 + r), 2u * c + 1u);
+          x = ga * __builtin_amdgcn_rcpf(ga + gb);
+        } else {
+          x = al * __builtin_amdgcn_rcpf(al + be);
+        }
+        if (logp) {
+          const float xc = qclamp(x, 0.01f, 0.99f);
+          lp = (al - 1.0f) * __logf(xc) + (be - 1.0f) * __logf(1.0f - xc) - (pol_lgamma(al) + pol_lgamma(be) - pol_lgamma(al + be));
+        }
       }
       if (actions && env0 + r < n_envs) actions[(size_t)(env0 + r) * AD + c] = x;
       if (act_lds) act_lds[r * AD + c] = x;  // fused rollouts: the env step of the same workgroup consumes it
-      if (logp && H <= POL_SCRATCH / POL_TILE) {
-        const float xc = qclamp(x, 0.01f, 0.99f);
-        scratch[r * H + c] = (al - 1.0f) * __logf(xc) + (be - 1.0f) * __logf(1.0f - xc) - (pol_lgamma(al) + pol_lgamma(be) - pol_lgamma(al + be));
-      }
+      if (logp && H <= POL_SCRATCH / POL_TILE) scratch[r * H + c] = lp;
     }
   }
   if (logp) {  // uniform over the workgroup

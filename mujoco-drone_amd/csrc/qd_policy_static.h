@@ -607,7 +607,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
         if (c.env0 + r < n_envs) aux[(size_t)(c.env0 + r) * NA + col] = lds[a_base + r * a_ld + col];
       }
   }
-  pol_outputs(lds + lg_base, ldl, NL, AD, c.env0, n_envs, c.tid, lds + ACT - POL_SCRATCH, smp, actions, logp, logits);
+  pol_outputs(lds + lg_base, ldl, NL, AD, c.env0, n_envs, c.tid, lds + ACT - POL_SCRATCH, smp, actions, logp, logits, nullptr, p.dist);
   POL_STAMP(2 + A::prog.n_ops);
 }
 

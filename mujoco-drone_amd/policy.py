@@ -467,10 +467,11 @@ _FAMILIES = {"CustomLSTM": _custom_lstm,
 
 def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4):
     """state dict -> (qd_policy_desc, qd_policy_op array, float32 weight blob); host only"""
-    if family not in _FAMILIES:
+    if not callable(family) and family not in _FAMILIES:
         raise ValueError("unknown policy family %r (have %s)" % (family, sorted(_FAMILIES)))
     prog = _Program(weights)
-    lay = _FAMILIES[family](prog, int(obs_dim), int(num_states), int(num_params), int(num_actions))
+    build = family if callable(family) else _FAMILIES[family]   # a callable builds its own layer program (same signature)
+    lay = build(prog, int(obs_dim), int(num_states), int(num_params), int(num_actions))
     d = L.QdPolicyDesc()
     d.n_ops, d.n_bufs = len(prog.ops), len(lay["widths"])
     for b, x in enumerate(lay["widths"]):
@@ -480,7 +481,7 @@ def compile_program(family, weights, obs_dim=22, num_states=16, num_params=6, nu
         d.ring[r].rows, d.ring[r].width, d.ring[r].period, d.ring[r].fill_off = rows, width, period, fill_off
     d.obs_dim, d.act_dim = int(obs_dim), int(num_actions)
     d.logits_buf, d.logits_off, d.n_logits = lay["logits"]
-    d.value_buf, d.value_off = lay["value"]
+    d.value_buf, d.value_off = lay.get("value", (-1, 0))
     if "aux" in lay:
         d.aux_buf, d.aux_off, d.aux_dim = lay["aux"]
     ops = (L.QdPolicyOp * len(prog.ops))(*prog.ops)
@@ -606,11 +607,16 @@ class DevicePolicy:
     actions = policy.forward(obs, prev_actions)               # [N,4] CUDA tensor; deterministic (Beta mean) action
     """
 
-    def __init__(self, family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4, device="cuda:0"):
+    DISTS = {"MyBetaDist": L.DIST_BETA, "MySquashedGaussian": L.DIST_SQUASHED_GAUSSIAN}   # distributions.py
+
+    def __init__(self, family, weights, obs_dim=22, num_states=16, num_params=6, num_actions=4, device="cuda:0", dist="MyBetaDist"):
         self.lib = L.lib()
         self.device = torch.device(device)
         self.family, self.obs_dim, self.act_dim = family, int(obs_dim), int(num_actions)
+        if dist not in self.DISTS:
+            raise ValueError("unknown action distribution %r (have %s)" % (dist, sorted(self.DISTS)))
         d, ops, blob = compile_program(family, weights, obs_dim, num_states, num_params, num_actions)
+        d.dist = self.DISTS[dist]                              # 'custom_action_dist' of the training scripts
         self.n_logits = int(d.n_logits)
         self.aux_dim = int(d.aux_dim)
         nbytes = self.lib.qd_policy_packed_bytes(C.byref(d), ops)

@@ -260,3 +260,23 @@ def beta_logp(logits, x):
     x = np.clip(np.asarray(x, np.float64), 1e-2, 1 - 1e-2)
     lp = (a - 1) * np.log(x) + (b - 1) * np.log1p(-x) - (gammaln(a) + gammaln(b) - gammaln(a + b))
     return lp.sum(-1)
+
+
+def squashed_gaussian_mean_action(logits):
+    """MySquashedGaussian.deterministic_sample (distributions.py:64-66, :103-106): sigmoid of the mean, clamped to [0, 1]"""
+    x = np.asarray(logits, np.float64)
+    mean = x[..., :x.shape[-1] // 2]
+    return np.clip(1.0 / (1.0 + np.exp(-mean)), 0.0, 1.0)
+
+
+def squashed_gaussian_logp(logits, x):
+    """MySquashedGaussian.logp (distributions.py:73-85 with _unsquash :108-112).  QUIRK: the class squashes with a sigmoid but
+    un-squashes with atanh(2 x - 1), which is half the pre-squash value; restated as written"""
+    lg = np.asarray(logits, np.float64)
+    h = lg.shape[-1] // 2
+    mean, log_std = lg[..., :h], np.clip(lg[..., h:], -5, 5)
+    std = np.exp(log_std)
+    th = np.clip(np.asarray(x, np.float64) * 2.0 - 1.0, -1.0 + 1e-4, 1.0 - 1e-4)
+    u = np.arctanh(th)
+    lp = -0.5 * ((u - mean) / std) ** 2 - log_std - 0.5 * np.log(2 * np.pi)
+    return np.clip(lp, -100, 100).sum(-1) - np.log(1 - th ** 2 + 1e-4).sum(-1)

@@ -334,6 +334,17 @@ def main():
     out["dsn_lstm_keys"] = np.array(list(sd.keys()))
     for k, v in sd.items():
         out["dsn_lstm/" + k] = v.numpy()
+    # MySquashedGaussian (distributions.py:41-119) on seeded logits: the deterministic action, and logp of given actions
+    from distributions import MySquashedGaussian
+    sg_logits = torch.randn((64, 8), generator=gen) * torch.tensor([1.5] * 4 + [2.5] * 4)
+    sg_logits[0, 4:] = torch.tensor([-9.0, 9.0, -5.0, 5.0])        # log_std beyond / at the clamp
+    sg_x = torch.rand((64, 4), generator=gen)
+    sg_x[1] = torch.tensor([0.0, 1.0, 1e-6, 1 - 1e-6])             # actions at the edge of the squashing range
+    with torch.no_grad():
+        dist = MySquashedGaussian(sg_logits, None)
+        sg_action = dist.deterministic_sample()
+        out["sg_logits"], out["sg_x"] = sg_logits.numpy(), sg_x.numpy()
+        out["sg_action"], out["sg_logp_action"], out["sg_logp_x"] = sg_action.numpy(), dist.logp(sg_action).numpy(), dist.logp(sg_x).numpy()
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "keys:", len(out), "bytes:", os.path.getsize(OUT))
 

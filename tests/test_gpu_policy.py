@@ -579,3 +579,41 @@ def test_recurrent_variants_vs_reference_models(PG, tag, family, kernel):
     got = logits.cpu().numpy()
     np.testing.assert_allclose(got[::2], PG[tag + "_logits"][::2, 0], atol=3e-5)
     assert np.abs(got[1::2] - PG[tag + "_logits"][1::2, 0]).max() > 1e-3        # the others carry their state on
+
+
+def _logits_passthrough(p, D, ns, npar, na):
+    """a one-op layer program: the observation row IS the logits row (to drive the output stage with chosen logits)"""
+    p.copy_obs(0, 2 * na, 0, 0)
+    p._put(np.zeros(4, dtype=np.float32))
+    return dict(widths=[16], logits=(0, 0, 2 * na))
+
+
+def test_squashed_gaussian_output_stage_vs_reference(PG):
+    """MySquashedGaussian on chosen logits: deterministic action and its log-probability against the reference class's own
+    numbers; sampled actions are sigmoid(N(mean, std)) (KS test on the standardised pre-squash values), reproducible from the
+    seed, and their log-probability equals the oracle's on the same (logits, action)"""
+    from scipy import stats
+    from mujoco_drone_amd.policy import DevicePolicy
+    from oracle import policy_ref as P
+    pol = DevicePolicy(_logits_passthrough, {}, obs_dim=8, dist="MySquashedGaussian")
+    lg = torch.tensor(PG["sg_logits"], device="cuda")
+    act, logp = pol.forward(lg, want_logp=True)
+    np.testing.assert_allclose(act.cpu().numpy(), PG["sg_action"], atol=2e-6)
+    np.testing.assert_allclose(logp.cpu().numpy(), PG["sg_logp_action"], rtol=2e-5, atol=2e-4)
+    n = 20000
+    rng = np.random.default_rng(4)
+    big = np.concatenate([rng.normal(scale=1.0, size=(n, 4)), rng.uniform(-1.5, 0.5, (n, 4))], axis=1).astype(np.float32)
+    bl = torch.tensor(big, device="cuda")
+    x1, lp1 = pol.forward(bl, explore=True, seed=7, counter=3, want_logp=True)
+    x2, _ = pol.forward(bl, explore=True, seed=7, counter=3, want_logp=True)
+    x3 = pol.forward(bl, explore=True, seed=7, counter=4)
+    assert torch.equal(x1, x2) and not torch.equal(x1, x3)
+    x = x1.cpu().numpy().astype(np.float64)
+    assert x.min() > 0 and x.max() < 1
+    z = (np.log(x / (1 - x)) - big[:, :4]) / np.exp(big[:, 4:])
+    for c in range(4):
+        assert stats.kstest(z[:, c], "norm").pvalue > 1e-3, c
+    assert abs(np.corrcoef(z[:, 0], z[:, 1])[0, 1]) < 0.03
+    np.testing.assert_allclose(lp1.cpu().numpy(), P.squashed_gaussian_logp(big, x1.cpu().numpy()), rtol=2e-4, atol=2e-3)
+    with pytest.raises(ValueError):
+        DevicePolicy(_logits_passthrough, {}, obs_dim=8, dist="Gaussian")

@@ -140,3 +140,12 @@ def test_every_family_program_passes_host_validation(PG, tag, family):
     d, ops, blob = compile_program(family, weights_of(PG, tag), **dims)
     assert L.lib().qd_policy_packed_bytes(C.byref(d), ops) > 0, L.last_error()
     assert d.n_logits == 8 and d.n_ops <= 32
+
+
+def test_squashed_gaussian_oracle_vs_reference_distribution(PG):
+    """MySquashedGaussian (the distribution the scripts import next to MyBetaDist): deterministic action and logp, incl. log_std
+    at the clamp and actions at the edge of the squashing range"""
+    from oracle import policy_ref as P
+    np.testing.assert_allclose(P.squashed_gaussian_mean_action(PG["sg_logits"]), PG["sg_action"], atol=2e-7)
+    for x, want in ((PG["sg_action"], PG["sg_logp_action"]), (PG["sg_x"], PG["sg_logp_x"])):
+        np.testing.assert_allclose(P.squashed_gaussian_logp(PG["sg_logits"], x), want, rtol=5e-5, atol=3e-5)   # float32 atanh at the clamp
