@@ -122,3 +122,19 @@ def test_error_translation(L):
     with pytest.raises(L.QdError):
         L.check(L.QD_ERR_HIP)
     L.check(0)
+
+
+def test_header_is_plain_c_and_the_c_example_links(tmp_path):
+    """include/qd.h must be consumable from C (the boundary is a C ABI): strict C99 syntax check of the header on its own, then the
+    plain-C example is compiled and linked against libqd.so (it is RUN by the GPU suite, tests/test_gpu_capi_example.py)"""
+    import subprocess
+    probe = tmp_path / "probe.c"
+    probe.write_text('#include "qd.h"\nint main(void) { qd_config c; (void)c; return qd_version() == QD_VERSION ? 0 : 1; }\n')
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Wextra", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), str(probe)])
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    if not os.path.exists(os.path.join(rocm, "include", "hip", "hip_runtime_api.h")):
+        pytest.skip("no HIP headers on this machine")
+    libdir = os.path.join(ROOT, "mujoco-drone_amd")
+    subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
+                           os.path.join(ROOT, "examples", "capi_hover.c"), "-o", str(tmp_path / "capi_hover"), "-L", libdir, "-lqd",
+                           "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib")])
