@@ -251,6 +251,9 @@ __device__ __forceinline__ void pool_fill(const KArgs& a, int i) {
   g[G_NX1 * np + i] = make_float4(s.qw, s.qx, s.qy, s.qz);
   g[G_NX2 * np + i] = make_float4(s.vx, s.vy, s.vz, s.th2);
   g[G_NX3 * np + i] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  // the tag goes last and after a release fence: an env lane of the same launch that sees it valid must see the four planes above
+  // (it reads them only after the tag, through a branch, so its side needs no fence)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
   g[G_NX4 * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(1u), 0.f);
 }
 
