@@ -49,3 +49,18 @@ def evaluate_trajectory(env, policy, trajectory, explore=False, seed=0):
     actions = list(out["actions"][:, 0].cpu().numpy().astype(np.float64))
     rewards = [float(x) for x in out["reward"][:, 0].cpu().numpy()]
     return observations, actions, rewards, out
+
+
+def evaluate_trajectory_lstmest(env, policy, trajectory, explore=False, seed=0):
+    """evaluation.py:76-132 rolls a (seq_len)-step observation / action history by hand on the host for the estimator networks; a
+    windowed `DevicePolicy` (`has_history`) keeps that history in per-env rings on the device, so this is `evaluate_trajectory` --
+    including the waypoint switching the reference's version left commented out (:106-110)."""
+    return evaluate_trajectory(env, policy, trajectory, explore=explore, seed=seed)
+
+
+def load_policy_state(checkpoint):
+    """evaluation.py:155-159: RLlib's pickled policy state of a checkpoint directory; its 'weights' dict is what `DevicePolicy` takes"""
+    import os
+    import pickle
+    with open(os.path.join(checkpoint, 'policies/default_policy/policy_state.pkl'), 'rb') as f:
+        return pickle.load(f)

@@ -142,3 +142,16 @@ def test_trajectory_generators_mirror_reference(golden):
     np.testing.assert_allclose(ci, G["traj_circle"], atol=1e-13)
     np.testing.assert_array_equal(ev.gen_step_trajectory()[1], G["traj_step_default"])
     np.testing.assert_allclose(ev.gen_ramp_trajectory()[1], G["traj_ramp_default"], atol=1e-13)
+
+
+def test_load_policy_state_reads_rllib_checkpoint_layout(tmp_path):
+    """evaluation.py:155-159: <checkpoint>/policies/default_policy/policy_state.pkl -> dict with 'weights'"""
+    import pickle
+    from mujoco_drone_amd.evaluation import load_policy_state, evaluate_trajectory_lstmest
+    d = tmp_path / "policies" / "default_policy"
+    d.mkdir(parents=True)
+    w = {"_logits.0._model.0.weight": np.ones((8, 4), dtype=np.float32)}
+    pickle.dump({"weights": w, "global_timestep": 7}, open(d / "policy_state.pkl", "wb"))
+    st = load_policy_state(str(tmp_path))
+    assert st["global_timestep"] == 7 and np.array_equal(st["weights"]["_logits.0._model.0.weight"], w["_logits.0._model.0.weight"])
+    assert callable(evaluate_trajectory_lstmest)
