@@ -6,7 +6,7 @@
 // of the near cap's rim, the matching point of the far cap, two more rim points at +-120 degrees) and the constraint constants
 // (solref 0.02 / 1, solimp 0.9 / 0.95 / 0.001 / 0.5 / 2, pyramidal friction cone with mu = 1, regulariser of a pyramid edge
 // R = 2 mu^2 (1 - d)/d (1 + mu^2) / m) restate MuJoCo's documentation and published source from memory; nothing under
-// /root/reference pins them.  What IS checked: the oracle solves the same convex problem by a different route (projected
+// /root/reference pins them.  What IS checked: the float64 checker of the test suite solves the same convex problem by a different route (projected
 // Gauss-Seidel on the dual, general Jacobians, full mass matrix) and the two agree; resting force = weight, critically damped
 // settling with the 0.02 s time constant, Coulomb sliding at mu g.
 //
