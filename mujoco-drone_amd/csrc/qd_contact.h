@@ -254,4 +254,25 @@ QD_HD int floor_contact(const Model<T>& M, const State<T>& s, double arm_len, do
   return cs.n;
 }
 
+// substep of the single-body model with the floor: forward, the floor's reaction, Euler advance; the accelerometer is
+// re-evaluated with the constrained accelerations (MuJoCo computes acceleration sensors after the constraint solve)
+template <class T>
+QD_HD V3<T> substep_floor(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h, double arm_len) {
+  Accel<T> ex, im;
+  V3<T> acc;
+  forward<T, false>(M, s, h, &ex, &im, &acc);
+  const V3<T> lin0 = ex.lin, ang0 = ex.ang;
+  const int n = floor_contact<T>(M, s, arm_len, (double)h, ex.lin, ex.ang, nullptr);
+  if (n > 0) {
+    // acc = R^T lin + g~ + alpha x r_s + w x (w x r_s) at the site r_s = (0, 0, sense_z): only the first and third term changed
+    const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+    const M3<T> R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
+    const V3<T> dl = mulT(R, mk<T>(ex.lin.x - lin0.x, ex.lin.y - lin0.y, ex.lin.z - lin0.z));
+    const T sz = T(Const::sense_z), dax = ex.ang.x - ang0.x, day = ex.ang.y - ang0.y;
+    acc = acc + dl + mk<T>(day * sz, -dax * sz, T(0));
+  }
+  integrate<T, false>(M, s, ex, c0, c1, c2, c3, h);
+  return acc;
+}
+
 }  // namespace qd
