@@ -45,7 +45,7 @@ class QdConfig(C.Structure):
         ("pend_rp_var", C.c_double * 2), ("pend_vel_var", C.c_double * 2),
         ("param_center", C.c_double * 6), ("param_width", C.c_double * 6), ("param_difficulty", C.c_double),
         ("seed", C.c_uint64),
-        ("ref_mode", C.c_int32), ("reserved0", C.c_int32), ("ref_radius", C.c_double), ("ref_frequency", C.c_double),
+        ("ref_mode", C.c_int32), ("floor_contact", C.c_int32), ("ref_radius", C.c_double), ("ref_frequency", C.c_double),
         ("ref_t0", C.c_double), ("ref_duration", C.c_double), ("ref_end", C.c_double * 4),
     ]
 

@@ -252,13 +252,9 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
   im->lin = mul(R, cvt<T>(a0im));
 }
 
-// one physics substep (mj_step with nstep = 1): forward, then Euler advance.
-// ctrl must already be clamped to [0,1].  Returns the accelerometer reading.
+// Euler advance of one substep with the accelerations `im`: activations, velocities, then positions with the NEW velocities
 template <class T, bool LOAD>
-QD_HD V3<T> substep(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h) {
-  Accel<T> ex, im;
-  V3<T> acc;
-  forward<T, LOAD>(M, s, h, &ex, &im, &acc);
+QD_HD void integrate(const Model<T>& M, State<T>& s, const Accel<T>& im, T c0, T c1, T c2, T c3, T h) {
   // activations: explicit Euler on act_dot = (ctrl - act)/tau, computed from the pre-step act
   const T ht = h * M.inv_tau;
   s.a0 += ht * (c0 - s.a0); s.a1 += ht * (c1 - s.a1); s.a2 += ht * (c2 - s.a2); s.a3 += ht * (c3 - s.a3);
@@ -287,6 +283,16 @@ QD_HD V3<T> substep(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h)
     qn = frsq(nw * nw + nx * nx + ny * ny + nz * nz);
     s.qw = nw * qn; s.qx = nx * qn; s.qy = ny * qn; s.qz = nz * qn;
   }
+}
+
+// one physics substep (mj_step with nstep = 1): forward, then Euler advance.
+// ctrl must already be clamped to [0,1].  Returns the accelerometer reading.
+template <class T, bool LOAD>
+QD_HD V3<T> substep(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h) {
+  Accel<T> ex, im;
+  V3<T> acc;
+  forward<T, LOAD>(M, s, h, &ex, &im, &acc);
+  integrate<T, LOAD>(M, s, im, c0, c1, c2, c3, h);
   return acc;
 }
 

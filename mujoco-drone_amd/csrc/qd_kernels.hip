@@ -25,6 +25,7 @@
 #include <new>
 
 #include "../../include/qd.h"
+#include "qd_contact.h"
 #include "qd_dynamics.h"
 #include "qd_math.h"
 #include "qd_model.h"
@@ -88,9 +89,10 @@ enum Spec {
   SPEC_RMA = 1,     // train_PPO.py / train_RMA.py: LocalFrameRPYParamsEnv + distance_energy_reward      (BASELINE cfg 3, 4)
   SPEC_LSTM = 2,    // train_LSTM.py: LocalFrameFullStateEnv + distance_energy_reward_pendulum_en4          (BASELINE cfg 5)
   SPEC_SIMPLE = 3,  // SimpleDrone.py: 6-value observation, drone-0 style reward / termination, direct ctrl (BASELINE cfg 1, 2)
-  SPEC_GENERIC_FS1 = 4  // any observation / reward (run-time dispatch) with the usual skip_steps = 1 fixed at compile time
+  SPEC_GENERIC_FS1 = 4,  // any observation / reward (run-time dispatch) with the usual skip_steps = 1 fixed at compile time
+  SPEC_FLOOR = 5         // SPEC_GENERIC of the single-body model with the floor contact (qd_contact.h), qd_config.floor_contact
 };
-template <int SPEC> constexpr bool spec_runtime() { return SPEC == SPEC_GENERIC || SPEC == SPEC_GENERIC_FS1; }
+template <int SPEC> constexpr bool spec_runtime() { return SPEC == SPEC_GENERIC || SPEC == SPEC_GENERIC_FS1 || SPEC == SPEC_FLOOR; }
 template <int SPEC> __device__ __forceinline__ int spec_obs(const KArgs& a) {
   return SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : SPEC == SPEC_LSTM ? (int)OBS_FULLSTATE : SPEC == SPEC_SIMPLE ? (int)OBS_SIMPLE : a.obs_kind;
 }
@@ -102,7 +104,7 @@ template <int SPEC> __device__ __forceinline__ int spec_term(const KArgs& a) {
 }
 // physics substeps per env step: compile-time in the specialisations (a run-time loop keeps the whole model and the
 // controls alive across the float64 core: +46 registers, every one of them an AGPR copy per use)
-template <int SPEC> constexpr int spec_frame_skip() { return SPEC == SPEC_SIMPLE ? 2 : SPEC == SPEC_GENERIC ? 0 : 1; }
+template <int SPEC> constexpr int spec_frame_skip() { return SPEC == SPEC_SIMPLE ? 2 : (SPEC == SPEC_GENERIC || SPEC == SPEC_FLOOR) ? 0 : 1; }
 template <int SPEC> __device__ __forceinline__ int spec_ctrl(const KArgs& a) {
   return SPEC == SPEC_SIMPLE ? (int)QD_CTRL_DIRECT : spec_runtime<SPEC>() ? a.ctrl_map : (int)QD_CTRL_AFFINE;
 }
@@ -389,7 +391,11 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
   if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
-  if (spec_frame_skip<SPEC>() == 1) {
+  if constexpr (SPEC == SPEC_FLOOR) {
+    static_assert(!LOAD, "floor contact is built for the single-body model");
+    const double arm_len = a.raw[(size_t)1 * a.npad + i];  // float64 raw parameter plane: the geom sizes are %.5g-rounded from it
+    for (int k = 0; k < a.frame_skip; k++) e.acc = substep_floor<float>(e.M, e.s, c0, c1, c2, c3, a.h, arm_len);
+  } else if (spec_frame_skip<SPEC>() == 1) {
     e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
   } else if (spec_frame_skip<SPEC>() == 2) {
     e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
@@ -1142,7 +1148,10 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   e->pc.load = e->load ? 1 : 0;
   e->regen = 0;
   e->spec = SPEC_GENERIC;
-  if (e->load && c->obs_kind == QD_OBS_RPY_PARAMS && c->reward_kind == QD_REW_DISTANCE_ENERGY && c->ctrl_map == QD_CTRL_AFFINE &&
+  if (c->floor_contact) {
+    if (e->load) { delete e; return fail(QD_ERR_UNSUPPORTED, "floor contact is built for the single-body model (no hanging load)"); }
+    e->spec = SPEC_FLOOR;
+  } else if (e->load && c->obs_kind == QD_OBS_RPY_PARAMS && c->reward_kind == QD_REW_DISTANCE_ENERGY && c->ctrl_map == QD_CTRL_AFFINE &&
       c->term_kind == QD_TERM_DEFAULT && c->frame_skip == 1)
     e->spec = SPEC_RMA;
   else if (e->load && c->obs_kind == QD_OBS_FULLSTATE && c->reward_kind == QD_REW_PEND_EN4 && c->ctrl_map == QD_CTRL_AFFINE &&
@@ -1302,6 +1311,7 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
     } else {                                                                 \
       if (env->spec == SPEC_SIMPLE) QD_STEP_LAUNCH(false, BLK, SPEC_SIMPLE); \
       else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC_FS1); \
+      else if (env->spec == SPEC_FLOOR) QD_STEP_LAUNCH(false, BLK, SPEC_FLOOR); \
       else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
     }                                                                        \
   } while (0)
@@ -1356,6 +1366,7 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
 
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
   QD_NEED(env);
+  if (env->spec == SPEC_FLOOR) return fail(QD_ERR_UNSUPPORTED, "multi-step kernels do not carry the floor contact: step with qd_step / qd_step_fragment");
   const KArgs& k = env->ka;
   if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
   if (T == 0) return QD_OK;
@@ -1397,6 +1408,7 @@ int qd_pid_action(qd_env* env, float* actions, void* stream) {
 
 int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out, void* stream) {
   QD_NEED(env);
+  if (env->spec == SPEC_FLOOR) return fail(QD_ERR_UNSUPPORTED, "multi-step kernels do not carry the floor contact: step with qd_step / qd_step_fragment");
   const KArgs& k = env->ka;
   if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
   if (T == 0) return QD_OK;

@@ -43,6 +43,7 @@ class SimpleDrone:
         c.ctrl_map, c.term_kind = L.CTRL_DIRECT, L.TERM_SIMPLE
         c.random_start = int(kwargs.get("random_start", L.START_SIMPLE))
         c.random_params, c.auto_reset, c.per_env_reference = 0, int(bool(kwargs.get("auto_reset", False))), 0
+        c.floor_contact = int(bool(kwargs.get("floor_contact", False)))   # extension: the floor of env_gen.py:97
         c.timestep = 1.0 / self.frequency
         c.max_distance = 0.5
         c.reference[:] = [float(x) for x in (list(self.reference) + [0.0])[:4]]

@@ -36,7 +36,7 @@ class OrcModel(C.Structure):
         ("rotor", (C.c_double * 3) * 4), ("gearF", C.c_double), ("gearT", C.c_double * 4), ("tau", C.c_double),
         ("sense", C.c_double * 3), ("anchor", C.c_double * 3), ("m1", C.c_double), ("I1", C.c_double),
         ("box1", C.c_double), ("m2", C.c_double), ("lc", C.c_double), ("I2", C.c_double * 3),
-        ("box2", C.c_double * 3),
+        ("box2", C.c_double * 3), ("raw", C.c_double * 6), ("invweight", (C.c_double * 2) * 3),
     ]
 
 
@@ -92,6 +92,12 @@ def _setup(lib):
     lib.orc_obs_dim.argtypes = [C.c_int, C.c_int]
     lib.orc_drone_state.restype = C.c_int
     lib.orc_step.argtypes = [C.POINTER(OrcModel), C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp]
+    lib.orc_step_floor.argtypes = [C.POINTER(OrcModel), C.c_double, C.c_int, _dp, _dp, _dp, _dp, _dp, _dp]
+    lib.orc_step_floor.restype = C.c_int
+    lib.orc_forward_floor.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, C.c_double, _dp, _dp]
+    lib.orc_forward_floor.restype = C.c_int
+    lib.orc_floor_contacts.argtypes = [C.POINTER(OrcModel), _dp, C.c_void_p]
+    lib.orc_floor_contacts.restype = C.c_int
     lib.orc_step.restype = None
     lib.orc_forward.argtypes = [C.POINTER(OrcModel), _dp, _dp, _dp, _dp, _dp, _dp, _dp]
     lib.orc_forward.restype = None
@@ -154,6 +160,34 @@ def step(model, h, nstep, qpos, qvel, act, ctrl):
     sensor = np.zeros(3)
     lib().orc_step(C.byref(model), float(h), int(nstep), _p(qpos), _p(qvel), _p(act), _p(ctrl), _p(sensor))
     return qpos, qvel, act, sensor
+
+
+class OrcContact(C.Structure):
+    _fields_ = [("pos", C.c_double * 3), ("dist", C.c_double), ("body", C.c_int)]
+
+
+def floor_contacts(model, qpos):
+    """contacts of the drone's geoms with the floor plane z = 0: list of (world position, signed distance, body)"""
+    qpos = _f64(qpos)
+    buf = (OrcContact * 64)()
+    n = lib().orc_floor_contacts(C.byref(model), _p(qpos), C.cast(buf, C.c_void_p))
+    return [(np.array(buf[i].pos[:]), buf[i].dist, buf[i].body) for i in range(n)]
+
+
+def forward_floor(model, qpos, qvel, act, h):
+    """qacc including the floor's reaction, number of contacts, normal force"""
+    qpos, qvel, act = _f64(qpos), _f64(qvel), _f64(act)
+    qacc, fz = np.zeros(8 if model.load else 6), np.zeros(1)
+    n = lib().orc_forward_floor(C.byref(model), _p(qpos), _p(qvel), _p(act), float(h), _p(qacc), _p(fz))
+    return qacc, n, float(fz[0])
+
+
+def step_floor(model, h, nstep, qpos, qvel, act, ctrl):
+    """orc_step with the floor contact: returns new (qpos, qvel, act, sensor, n_contacts, normal force)"""
+    qpos, qvel, act, ctrl = _f64(qpos).copy(), _f64(qvel).copy(), _f64(act).copy(), _f64(ctrl)
+    sensor, fz = np.zeros(3), np.zeros(1)
+    n = lib().orc_step_floor(C.byref(model), float(h), int(nstep), _p(qpos), _p(qvel), _p(act), _p(ctrl), _p(sensor), _p(fz))
+    return qpos, qvel, act, sensor, n, float(fz[0])
 
 
 def mass_matrix(model, qpos):

@@ -216,6 +216,7 @@ static void inertia_box_dims(const double I[3], double mass, double box[3]) {
   box[2] = sqrt(fmax(MJMINVAL, I[0] + I[1] - I[2]) / mass * 6.0);
 }
 
+static void floor_invweight(OrcModel *o);
 void orc_build_model(const double raw[6], OrcModel *o) {
   memset(o, 0, sizeof *o);
   const double mass = raw[0], arm_len = raw[1], motor_force = raw[2], motor_tau = raw[3];
@@ -306,6 +307,8 @@ void orc_build_model(const double raw[6], OrcModel *o) {
     o->I2[0] = t2[0]; o->I2[1] = t2[1]; o->I2[2] = t2[2];
     inertia_box_dims(o->I2, o->m2, o->box2);
   }
+  memcpy(o->raw, raw, sizeof o->raw);
+  floor_invweight(o);
 }
 
 /* ---------------------------------------------------------- dynamics */
@@ -1050,6 +1053,324 @@ void orc_batch_step(const OrcBatchCfg *c, const OrcModel *models, const double *
 }
 
 /* ------------------------------------------------ analytic PID cascade (8f-3) */
+/* ================================================================ SURVEY 8f(1): floor contact (see qd_oracle.h) */
+/* body poses in the world from qpos: R of each body and the hinge anchor */
+static void floor_body_frames(const OrcModel *m, const double *qpos, double Rb[3][9], double xb[3][3]) {
+  double q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+  quat_norm(q);
+  orc_quat2dcm(q, Rb[0]);
+  for (int k = 0; k < 3; k++) xb[0][k] = qpos[k];
+  if (m->load) {
+    double Rx[9], Ry[9], t[3];
+    rotx(qpos[7], Rx);
+    roty(qpos[8], Ry);
+    m3m(Rb[0], Rx, Rb[1]);
+    m3m(Rb[1], Ry, Rb[2]);
+    m3v(Rb[0], m->anchor, t);
+    for (int k = 0; k < 3; k++) xb[1][k] = xb[2][k] = qpos[k] + t[k];
+  }
+}
+
+static void floor_push(OrcContact *out, int *cnt, const double pos[3], double dist, int body) {
+  if (*cnt >= ORC_MAX_CONTACTS) return;
+  memcpy(out[*cnt].pos, pos, 3 * sizeof(double));
+  out[*cnt].dist = dist;
+  out[*cnt].body = body;
+  (*cnt)++;
+}
+
+/* plane z = 0 against a box (mjc_PlaneBox): corners in the order x sign = bit 0, y = bit 1, z = bit 2; a corner counts when it is
+ * below the plane and not above the box centre; at most four */
+static void floor_box(const double c[3], const double Rg[9], const double size[3], int body, OrcContact *out, int *cnt) {
+  int n = 0;
+  for (int i = 0; i < 8 && n < 4; i++) {
+    const double v[3] = {(i & 1 ? size[0] : -size[0]), (i & 2 ? size[1] : -size[1]), (i & 4 ? size[2] : -size[2])};
+    double corner[3];
+    m3v(Rg, v, corner);
+    const double ldist = corner[2];
+    if (c[2] + ldist > 0 || ldist > 0) continue;
+    const double dist = c[2] + ldist;
+    const double pos[3] = {c[0] + corner[0], c[1] + corner[1], c[2] + corner[2] - 0.5 * dist};
+    floor_push(out, cnt, pos, dist, body);
+    n++;
+  }
+}
+
+static void floor_sphere(const double c[3], double r, int body, OrcContact *out, int *cnt) {
+  const double dist = c[2] - r;
+  if (dist > 0) return;
+  const double pos[3] = {c[0], c[1], c[2] - r - 0.5 * dist};
+  floor_push(out, cnt, pos, dist, body);
+}
+
+/* plane against a cylinder (mjc_PlaneCylinder): the deepest point of the near cap's rim, the matching point of the far cap, and two
+ * more rim points of the near cap at +-120 degrees */
+static void floor_cylinder(const double c[3], const double Rg[9], double radius, double hh, int body, OrcContact *out, int *cnt) {
+  const double nrm[3] = {0, 0, 1};
+  double axis[3] = {Rg[2], Rg[5], Rg[8]};
+  double prjaxis = axis[2];
+  if (prjaxis > 0) { for (int k = 0; k < 3; k++) axis[k] = -axis[k]; prjaxis = -prjaxis; }
+  const double dist0 = c[2];
+  double vec[3] = {axis[0] * prjaxis - nrm[0], axis[1] * prjaxis - nrm[1], axis[2] * prjaxis - nrm[2]};
+  double len = sqrt(v3dot(vec, vec));
+  if (len < 1e-12) { vec[0] = Rg[0] * radius; vec[1] = Rg[3] * radius; vec[2] = Rg[6] * radius; }   /* disk parallel to the plane */
+  else for (int k = 0; k < 3; k++) vec[k] *= radius / len;
+  const double prjvec = vec[2];
+  for (int k = 0; k < 3; k++) axis[k] *= hh;
+  prjaxis *= hh;
+  if (dist0 + prjaxis + prjvec > 0) return;
+  {
+    const double d = dist0 + prjaxis + prjvec;
+    const double pos[3] = {c[0] + vec[0] + axis[0], c[1] + vec[1] + axis[1], c[2] + vec[2] + axis[2] - 0.5 * d};
+    floor_push(out, cnt, pos, d, body);
+  }
+  if (dist0 - prjaxis + prjvec <= 0) {
+    const double d = dist0 - prjaxis + prjvec;
+    const double pos[3] = {c[0] + vec[0] - axis[0], c[1] + vec[1] - axis[1], c[2] + vec[2] - axis[2] - 0.5 * d};
+    floor_push(out, cnt, pos, d, body);
+  }
+  const double prjvec1 = -0.5 * prjvec;
+  if (dist0 + prjaxis + prjvec1 <= 0) {
+    double vec1[3];
+    v3cross(vec, axis, vec1);
+    double l1 = sqrt(v3dot(vec1, vec1));
+    if (l1 > 1e-12) for (int k = 0; k < 3; k++) vec1[k] *= radius * sqrt(3.0) * 0.5 / l1;
+    const double d = dist0 + prjaxis + prjvec1;
+    for (int sgn = 1; sgn >= -1; sgn -= 2) {
+      const double pos[3] = {c[0] + sgn * vec1[0] + axis[0] - 0.5 * vec[0], c[1] + sgn * vec1[1] + axis[1] - 0.5 * vec[1],
+                             c[2] + sgn * vec1[2] + axis[2] - 0.5 * vec[2] - 0.5 * d};
+      floor_push(out, cnt, pos, d, body);
+    }
+  }
+}
+
+int orc_floor_contacts(const OrcModel *m, const double *qpos, OrcContact *out) {
+  double Rb[3][9], xb[3][3];
+  floor_body_frames(m, qpos, Rb, xb);
+  int cnt = 0;
+  const double hb = 0.05, al = m->raw[1];
+  const double Id[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+  /* a geom of body b: centre and orientation in the world */
+#define GEOM(b, px, py, pz, Rl)                                   \
+  double lp[3] = {px, py, pz}, c[3], Rg[9];                       \
+  m3v(Rb[b], lp, c);                                              \
+  for (int k = 0; k < 3; k++) c[k] += xb[b][k];                   \
+  m3m(Rb[b], Rl, Rg);
+  { GEOM(0, 0, 0, 0, Id) const double sz[3] = {orc_round5g(hb), orc_round5g(hb), orc_round5g(hb / 3)}; floor_box(c, Rg, sz, 0, out, &cnt); }
+  { GEOM(0, orc_round5g(hb + hb / 3), 0, 0, Id)
+    const double sz[3] = {orc_round5g(hb / 3), orc_round5g(0.15 * hb), orc_round5g(0.15 * hb)}; floor_box(c, Rg, sz, 0, out, &cnt); }
+  for (int i = 0; i < 4; i++) {
+    const double theta = i * PI / 2 - PI / 4;
+    const double A = sqrt(2.0) * hb + 0.5 * al, B = sqrt(2.0) * hb + al;
+    double Rz[9];
+    rotz(orc_round5g(theta), Rz);
+    { GEOM(0, orc_round5g(A * cos(theta)), orc_round5g(A * sin(theta)), 0, Rz)
+      const double sz[3] = {orc_round5g(al / 2), orc_round5g(al / 20), orc_round5g(al / 20)}; floor_box(c, Rg, sz, 0, out, &cnt); }
+    { GEOM(0, orc_round5g(B * cos(theta)), orc_round5g(B * sin(theta)), orc_round5g(0.015), Id)
+      floor_cylinder(c, Rg, orc_round5g(0.01), orc_round5g(0.01), 0, out, &cnt); }
+    { GEOM(0, orc_round5g(B * cos(theta)), orc_round5g(B * sin(theta)), orc_round5g(0.025), Id)
+      floor_cylinder(c, Rg, orc_round5g(al / 1.5), orc_round5g(0.0025), 0, out, &cnt); }
+  }
+  if (m->load) {
+    const double pl = m->raw[4], wm = m->raw[5];
+    floor_sphere(xb[1], orc_round5g(0.02), 1, out, &cnt);
+    { GEOM(2, 0, 0, orc_round5g(-pl / 2), Id) floor_cylinder(c, Rg, orc_round5g(0.005), orc_round5g(pl / 2), 2, out, &cnt); }
+    { GEOM(2, 0, 0, orc_round5g(-pl), Id)
+      const double bs = orc_round5g(0.1 * cbrt(wm)); const double sz[3] = {bs, bs, bs}; floor_box(c, Rg, sz, 2, out, &cnt); }
+  }
+#undef GEOM
+  return cnt;
+}
+
+/* Jacobian of a world point x rigidly attached to body b: 3 x nv (MuJoCo free-joint convention of dyn_terms) */
+static void floor_point_jac(const OrcModel *m, const double *qpos, const double Rb[3][9], const double xb[3][3], int b,
+                            const double x[3], double J[3][8]) {
+  memset(J, 0, 3 * 8 * sizeof(double));
+  for (int j = 0; j < 3; j++) J[j][j] = 1.0;
+  for (int j = 0; j < 3; j++) {
+    const double a[3] = {Rb[0][j], Rb[0][3 + j], Rb[0][6 + j]}, r[3] = {x[0] - qpos[0], x[1] - qpos[1], x[2] - qpos[2]};
+    double t[3];
+    v3cross(a, r, t);
+    for (int k = 0; k < 3; k++) J[k][3 + j] = t[k];
+  }
+  if (m->load && b >= 1) {
+    const double r[3] = {x[0] - xb[1][0], x[1] - xb[1][1], x[2] - xb[1][2]};
+    const double a1[3] = {Rb[0][0], Rb[0][3], Rb[0][6]}, a2[3] = {Rb[1][1], Rb[1][4], Rb[1][7]};
+    double t[3];
+    v3cross(a1, r, t);
+    for (int k = 0; k < 3; k++) J[k][6] = t[k];
+    if (b == 2) { v3cross(a2, r, t); for (int k = 0; k < 3; k++) J[k][7] = t[k]; }
+  }
+}
+
+/* body_invweight0 (mj_setConst): at qpos0, A = J M^-1 J^T with J the 6 x nv Jacobian of the body's COM; mean diagonal of the
+ * translational and of the rotational block */
+static void floor_invweight(OrcModel *o) {
+  double qpos[9] = {0, 0, 0, 1, 0, 0, 0, 0, 0}, qvel[8] = {0}, act[4] = {0};
+  Dyn d;
+  dyn_terms(o, qpos, qvel, act, &d);
+  double Rb[3][9], xb[3][3];
+  floor_body_frames(o, qpos, Rb, xb);
+  const int nb = o->load ? 3 : 1, nv = d.nv;
+  for (int b = 0; b < nb; b++) {
+    double com[3];
+    if (b == 0) { m3v(Rb[0], o->c0, com); }
+    else if (b == 1) { memcpy(com, xb[1], sizeof com); }
+    else { const double dn[3] = {0, 0, -o->lc}; m3v(Rb[2], dn, com); for (int k = 0; k < 3; k++) com[k] += xb[2][k]; }
+    double Jt[3][8], Jr[3][8];
+    floor_point_jac(o, qpos, Rb, xb, b, com, Jt);
+    memset(Jr, 0, sizeof Jr);
+    for (int j = 0; j < 3; j++) for (int k = 0; k < 3; k++) Jr[k][3 + j] = Rb[0][3 * k + j];
+    if (o->load && b >= 1) { for (int k = 0; k < 3; k++) Jr[k][6] = Rb[0][3 * k]; if (b == 2) for (int k = 0; k < 3; k++) Jr[k][7] = Rb[1][3 * k + 1]; }
+    double tr = 0, ro = 0;
+    for (int k = 0; k < 3; k++) {
+      double x[8];
+      spd_solve(d.M, nv, Jt[k], x);
+      for (int i = 0; i < nv; i++) tr += Jt[k][i] * x[i];
+      spd_solve(d.M, nv, Jr[k], x);
+      for (int i = 0; i < nv; i++) ro += Jr[k][i] * x[i];
+    }
+    o->invweight[b][0] = tr / 3;
+    o->invweight[b][1] = ro / 3;
+  }
+}
+
+/* solimp (0.9, 0.95, 0.001, 0.5, 2): impedance as a function of the penetration */
+static double floor_impedance(double r) {
+  double x = fabs(r) / 0.001;
+  if (x > 1) x = 1;
+  const double y = x <= 0.5 ? 2 * x * x : 1 - 2 * (1 - x) * (1 - x);
+  return 0.9 + y * (0.95 - 0.9);
+}
+
+/* adds the floor's reaction to the smooth acceleration qacc (in place); returns the number of contacts, *fz the normal force */
+static int floor_solve(const OrcModel *m, const Dyn *dp, const double *qpos, const double *qvel, double h, double *qacc, double *fzp) {
+  static __thread double A[4 * ORC_MAX_CONTACTS][4 * ORC_MAX_CONTACTS];
+  const Dyn d = *dp;
+  const int nv = d.nv;
+  int ncon = 0;
+    OrcContact con[ORC_MAX_CONTACTS];
+    ncon = orc_floor_contacts(m, qpos, con);
+    double fz = 0;
+    int ne = 0;
+    static __thread double Jr[4 * ORC_MAX_CONTACTS][8], MiJ[4 * ORC_MAX_CONTACTS][8], bvec[4 * ORC_MAX_CONTACTS], Rr[4 * ORC_MAX_CONTACTS],
+        f[4 * ORC_MAX_CONTACTS];
+    if (ncon > 0) {
+      double Rb[3][9], xb[3][3];
+      floor_body_frames(m, qpos, Rb, xb);
+      const double mu = 1.0, tc = fmax(0.02, 2 * h), dmax = 0.95;
+      const double kb = 2.0 / (dmax * tc), kk = 1.0 / (dmax * dmax * tc * tc);
+      for (int c = 0; c < ncon; c++) {
+        if (!(con[c].dist < 0)) continue;
+        double Jp[3][8];
+        floor_point_jac(m, qpos, Rb, xb, con[c].body, con[c].pos, Jp);
+        const double imp = floor_impedance(con[c].dist);
+        const double diag = m->invweight[con[c].body][0] * (1 + mu * mu);
+        const double Rpy = 2 * mu * mu * fmax(1e-15, (1 - imp) / imp * diag);
+        /* contact frame: normal z, tangents y and -x (mju_makeFrame on (0,0,1)) */
+        const double dir[4][3] = {{0, mu, 1}, {0, -mu, 1}, {-mu, 0, 1}, {mu, 0, 1}};
+        for (int e = 0; e < 4; e++) {
+          double vel = 0;
+          for (int i = 0; i < nv; i++) {
+            Jr[ne][i] = dir[e][0] * Jp[0][i] + dir[e][1] * Jp[1][i] + dir[e][2] * Jp[2][i];
+            vel += Jr[ne][i] * qvel[i];
+          }
+          const double aref = -kb * vel - kk * imp * con[c].dist;
+          double a0 = 0;
+          for (int i = 0; i < nv; i++) a0 += Jr[ne][i] * qacc[i];
+          bvec[ne] = a0 - aref;
+          Rr[ne] = Rpy;
+          spd_solve(d.M, nv, Jr[ne], MiJ[ne]);
+          f[ne] = 0;
+          ne++;
+        }
+      }
+      for (int i = 0; i < ne; i++)
+        for (int j = 0; j < ne; j++) {
+          double a = 0;
+          for (int k = 0; k < nv; k++) a += Jr[i][k] * MiJ[j][k];
+          A[i][j] = a;
+        }
+      /* projected Gauss-Seidel on  min 1/2 f^T (A + R) f + f^T b,  f >= 0 */
+      for (int it = 0; it < 20000; it++) {
+        double change = 0;
+        for (int i = 0; i < ne; i++) {
+          double g = bvec[i] + Rr[i] * f[i];
+          for (int j = 0; j < ne; j++) g += A[i][j] * f[j];
+          double fn = f[i] - g / (A[i][i] + Rr[i]);
+          if (fn < 0) fn = 0;
+          change = fmax(change, fabs(fn - f[i]));
+          f[i] = fn;
+        }
+        if (change < 1e-13) break;
+      }
+      for (int i = 0; i < ne; i++) {
+        for (int k = 0; k < nv; k++) qacc[k] += MiJ[i][k] * f[i];
+        fz += f[i];   /* every pyramid edge has a unit normal component */
+      }
+    }
+  *fzp = fz;
+  return ncon;
+}
+
+/* mj_forward with the floor: qacc incl. the contact reaction */
+int orc_forward_floor(const OrcModel *m, const double *qpos, const double *qvel, const double act[4], double h, double *qacc,
+                      double *contact_force_z) {
+  Dyn d;
+  dyn_terms(m, qpos, qvel, act, &d);
+  double rhs[8], fz = 0;
+  for (int i = 0; i < d.nv; i++) rhs[i] = d.Q[i] - d.bias[i];
+  spd_solve(d.M, d.nv, rhs, qacc);
+  const int n = floor_solve(m, &d, qpos, qvel, h, qacc, &fz);
+  if (contact_force_z) *contact_force_z = fz;
+  return n;
+}
+
+int orc_step_floor(const OrcModel *m, double h, int nstep, double *qpos, double *qvel, double act[4], const double ctrl[4],
+                   double sensor[3], double *contact_force_z) {
+  int ncon = 0;
+  for (int s = 0; s < nstep; s++) {
+    Dyn d;
+    dyn_terms(m, qpos, qvel, act, &d);
+    const int nv = d.nv;
+    double rhs[8], qacc[8], qimp[8], act_dot[4], fz = 0;
+    for (int i = 0; i < nv; i++) rhs[i] = d.Q[i] - d.bias[i];
+    spd_solve(d.M, nv, rhs, qacc);
+    ncon = floor_solve(m, &d, qpos, qvel, h, qacc, &fz);
+    if (contact_force_z) *contact_force_z = fz;
+    accel_sensor(m, &d, qacc, sensor);
+    for (int r = 0; r < 4; r++) act_dot[r] = (clamp01(ctrl[r]) - act[r]) / fmax(m->tau, MJMINVAL);
+    if (m->load) {  /* (M + h D) qimp = M qacc, constraint forces included */
+      double Mh[64], rt[8];
+      memcpy(Mh, d.M, sizeof Mh);
+      for (int i = 0; i < nv; i++) { rt[i] = 0; for (int j = 0; j < nv; j++) rt[i] += d.M[8 * i + j] * qacc[j]; }
+      if (fz == 0) memcpy(rt, rhs, sizeof rt);  /* no contact force: exactly orc_step */
+      Mh[8 * 6 + 6] += h * m->damping;
+      Mh[8 * 7 + 7] += h * m->damping;
+      spd_solve(Mh, nv, rt, qimp);
+    } else {
+      memcpy(qimp, qacc, sizeof qimp);
+    }
+    for (int r = 0; r < 4; r++) act[r] += h * act_dot[r];
+    for (int i = 0; i < nv; i++) qvel[i] += h * qimp[i];
+    for (int k = 0; k < 3; k++) qpos[k] += h * qvel[k];
+    {
+      double q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+      quat_norm(q);
+      double wn = sqrt(qvel[3] * qvel[3] + qvel[4] * qvel[4] + qvel[5] * qvel[5]);
+      double ax[3] = {1, 0, 0};
+      if (wn >= MJMINVAL) { ax[0] = qvel[3] / wn; ax[1] = qvel[4] / wn; ax[2] = qvel[5] / wn; } else wn = 0;
+      double ang = h * wn, sn = sin(ang / 2);
+      double qr[4] = {cos(ang / 2), ax[0] * sn, ax[1] * sn, ax[2] * sn}, qn[4];
+      quat_mul(q, qr, qn);
+      quat_norm(qn);
+      for (int k = 0; k < 4; k++) qpos[3 + k] = qn[k];
+    }
+    if (m->load) { qpos[7] += h * qvel[6]; qpos[8] += h * qvel[7]; }
+  }
+  return ncon;
+}
+
 static double clip3(double x, double lo, double hi) { return x < lo ? lo : (x > hi ? hi : x); }
 void orc_pid_reset(OrcPid *c) {
   memset(c, 0, sizeof *c);

@@ -77,6 +77,8 @@ typedef struct OrcModel {
   double m2, lc;          /* mass, COM distance below the anchor             */
   double I2[3];           /* Ixx,Iyy,Izz about COM in pendulum frame         */
   double box2[3];
+  double raw[6];          /* the six parameters the model was built from (floor contact: geom sizes) */
+  double invweight[3][2]; /* MuJoCo body_invweight0 of core / link / pendulum: translational, rotational     */
 } OrcModel;
 
 /* %.5g round trip (env_gen.py:129 to_xml_string(precision=5)) */
@@ -162,6 +164,27 @@ void orc_batch_step(const OrcBatchCfg *c, const OrcModel *models, const double *
                     double *qpos, double *qvel, double *act, double *sensor, long *num_steps,
                     const double *actions, double *obs, double *reward, unsigned char *trunc,
                     int threads);
+
+/* ---- contact of the drone's geoms (env_gen.py:41-72) with the floor plane z = 0 (env_gen.py:97) in the manner
+ * of MuJoCo's soft-constraint contact model.  PARITY UNPINNED like the rest of the physics, and more so: the contact
+ * generation rules (plane-box: corners below the box centre, at most 4; plane-cylinder: deepest rim point, far cap, two points
+ * at 120 degrees; plane-sphere) and the constraint constants (solref 0.02 / 1, solimp 0.9 / 0.95 / 0.001 / 0.5 / 2, pyramidal
+ * cone with mu = 1, diagApprox from body_invweight0, R of a pyramid edge = 2 mu^2 (1 - d)/d (1 + mu^2) invweight) are
+ * restated from MuJoCo's documentation and published source from memory; nothing in the reference pins them.  The solver is
+ * a projected Gauss-Seidel on the dual (the product uses a Newton method on the primal: two routes to the same minimiser). */
+typedef struct OrcContact {
+  double pos[3];  /* world position (midway between the surfaces, as MuJoCo places it) */
+  double dist;    /* signed distance, < 0 penetrating */
+  int    body;    /* 0 core, 1 link, 2 pendulum */
+} OrcContact;
+#define ORC_MAX_CONTACTS 64
+int orc_floor_contacts(const OrcModel *m, const double *qpos, OrcContact *out);
+/* orc_step with the floor: qacc = argmin of MuJoCo's convex contact problem; returns the number of contacts of the last substep */
+/* mj_forward with the floor: qacc including the contact reaction (h enters through solref's 2 h floor on the time constant) */
+int orc_forward_floor(const OrcModel *m, const double *qpos, const double *qvel, const double act[4], double h, double *qacc,
+                      double *contact_force_z);
+int orc_step_floor(const OrcModel *m, double h, int nstep, double *qpos, double *qvel, double act[4],
+                   const double ctrl[4], double sensor[3], double *contact_force_z);
 
 /* ---- the analytic cascaded PID used as a closed-loop action source
  * (models/Analytic/PositionController.py:6-34, AttitudeController.py:7-55,

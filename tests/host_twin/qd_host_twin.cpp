@@ -148,3 +148,38 @@ void twin_pid_f32(double* st13, const double* ref, const double* xyz, const doub
   run_pid<float>(st13, ref, xyz, rpy, mass, force, pos_action, rpyz, ctrl, action);
 }
 }
+
+// ---- floor contact twin (float64 instantiation of qd_contact.h), single-body model ----
+#include "qd_contact.h"
+extern "C" {
+// contacts of the drone's geoms with the floor: out[4 * i + {0,1,2,3}] = x, y, z, dist; returns the count
+int twin_floor_contacts(double arm_len, const double* qpos, double* out) {
+  double q[4] = {qpos[3], qpos[4], qpos[5], qpos[6]};
+  const double n = 1.0 / sqrt(q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3]);
+  const double w = q[0] * n, x = q[1] * n, y = q[2] * n, z = q[3] * n;
+  const double R[9] = {1 - 2 * (y * y + z * z), 2 * (x * y - w * z), 2 * (x * z + w * y), 2 * (x * y + w * z), 1 - 2 * (x * x + z * z),
+                       2 * (y * z - w * x), 2 * (x * z - w * y), 2 * (y * z + w * x), 1 - 2 * (x * x + y * y)};
+  ContactSet cs;
+  contact_generate(cs, arm_len, qpos, R);
+  for (int i = 0; i < cs.n; i++) { out[4 * i] = cs.x[i]; out[4 * i + 1] = cs.y[i]; out[4 * i + 2] = cs.z[i]; out[4 * i + 3] = cs.r[i]; }
+  return cs.n;
+}
+// qacc (6) of the single-body model including the floor's reaction; returns the number of contacts
+int twin_forward_floor(const double* model16, double arm_len, const double* qpos, const double* qvel, const double* act, double h,
+                       double* qacc, double* force_z) {
+  Model<double> M;
+  double* mp = reinterpret_cast<double*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = model16[i];
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = s.th2 = s.thd1 = s.thd2 = 0;
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  Accel<double> ex, im;
+  V3<double> acc;
+  forward<double, false>(M, s, h, &ex, &im, &acc);
+  const int n = floor_contact<double>(M, s, arm_len, h, ex.lin, ex.ang, force_z);
+  qacc[0] = ex.lin.x; qacc[1] = ex.lin.y; qacc[2] = ex.lin.z; qacc[3] = ex.ang.x; qacc[4] = ex.ang.y; qacc[5] = ex.ang.z;
+  return n;
+}
+}

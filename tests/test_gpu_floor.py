@@ -1,0 +1,152 @@
+"""GPU parity of the floor contact (qd_config.floor_contact) against the float64 oracle, which solves the same convex
+contact problem by a different route (dual projected Gauss-Seidel, general Jacobians).  PARITY UNPINNED like the rest of the
+physics: no MuJoCo here.  The device keeps the state in float32 and solves the contact problem in float64; measured differences
+to the oracle are 1e-8 ... 1e-6 m over hundreds of steps with impacts, the tolerances below leave an order of magnitude."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from test_gpu_parity import make_cfg, rand_raw, CENTER  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def qd():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import types
+    from mujoco_drone_amd import _lib
+    from mujoco_drone_amd.environments import _device
+    _lib.lib()
+    return types.SimpleNamespace(_lib=_lib, dev=_device)
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+def _floor_env(qd, n, frame_skip=2, h=0.001, **kw):
+    c = make_cfg(qd._lib, n, load=False, obs="BaseDroneEnv", reward="default_reward_fcn", frame_skip=frame_skip, h=h, ctrl_map=0,
+                 max_steps=10 ** 6, max_distance=1e9, ref=(0, 0, 0.1, 0), start_pos=(0, 0, 0.1, 0), **kw)
+    c.floor_contact = 1
+    return qd.dev.DeviceEnv(c)
+
+
+def test_drop_and_rest_vs_oracle(qd, orc):
+    """SimpleDrone's integration settings (1 kHz, 2 substeps): level drones dropped from 1-6 cm with the rotors off land on the core
+    box, rebound once and settle; whole trajectory against the oracle, rest height / force balance at the end"""
+    n, steps = 64, 400
+    rng = np.random.default_rng(3)
+    raw = rand_raw(rng, n, False)
+    env = _floor_env(qd, n)
+    env.set_params(raw)
+    qpos = np.zeros((n, 7)); qpos[:, 3] = 1
+    qpos[:, 0:2] = rng.normal(scale=0.5, size=(n, 2)); qpos[:, 2] = 0.016667 + rng.uniform(0.01, 0.06, n)
+    qvel = np.zeros((n, 6))
+    env.set_state(qpos, qvel, np.zeros((n, 4)))
+    models = [orc.build_model(r) for r in raw]
+    oq = [qpos[i].astype(np.float32).astype(np.float64) for i in range(n)]
+    ov = [np.zeros(6) for _ in range(n)]; oa = [np.zeros(4) for _ in range(n)]
+    zero = torch.zeros((n, 4), device="cuda")
+    worst_p = worst_v = 0.0
+    for t in range(steps):
+        env.step(zero)
+        for i in range(n):
+            oq[i], ov[i], oa[i], _, _, _ = orc.step_floor(models[i], 0.001, 2, oq[i], ov[i], oa[i], np.zeros(4))
+        if t % 10 == 9 or t == steps - 1:
+            gq, gv, _, gs, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+            worst_p = max(worst_p, float(np.abs(gq - np.array(oq)).max()))
+            worst_v = max(worst_v, float(np.abs(gv - np.array(ov)).max()))
+    print("drop test: worst |dpos| %.2e  |dvel| %.2e" % (worst_p, worst_v))
+    assert worst_p < 2e-6 and worst_v < 5e-5                                   # measured: 3e-8 m, 5e-7 m/s
+    gq, gv, _, gs, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    np.testing.assert_allclose(gq, np.array(oq), atol=5e-6)                  # at rest
+    assert np.abs(gv).max() < 1e-3
+    pen = 0.016667 - gq[:, 2]
+    assert np.all(pen > 0) and np.all(pen < 5e-4)
+    np.testing.assert_allclose(gs, np.tile([0, 0, 9.81], (n, 1)), atol=0.05)   # accelerometer: specific force +g on the floor
+
+
+def test_tilted_landings_with_velocity_vs_oracle(qd, orc):
+    """arbitrary attitudes and velocities near the floor: arms, motors and propeller disks (cylinders) touch first, the drone
+    tumbles / slides with friction; short horizon (contact-rich motion amplifies rounding) against the oracle, then invariants
+    at the end of a longer run: everything finite, nobody falls through, energy is gone"""
+    n, steps = 128, 60
+    rng = np.random.default_rng(4)
+    raw = rand_raw(rng, n, False)
+    env = _floor_env(qd, n)
+    env.set_params(raw)
+    qpos = np.zeros((n, 7))
+    ang = rng.normal(scale=0.5, size=(n, 3)); ang[:, 2] = rng.uniform(-3, 3, n)
+    for i in range(n):
+        qpos[i, 3:7] = orc.rpy2quat(ang[i])
+    qpos[:, 0:2] = rng.normal(scale=0.3, size=(n, 2)); qpos[:, 2] = rng.uniform(0.05, 0.25, n)
+    qvel = np.concatenate([rng.normal(scale=0.5, size=(n, 2)), -rng.uniform(0.2, 1.5, (n, 1)), rng.normal(scale=1.0, size=(n, 3))], axis=1)
+    env.set_state(qpos, qvel, np.zeros((n, 4)))
+    models = [orc.build_model(r) for r in raw]
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    oq = [f32(qpos[i]) for i in range(n)]; ov = [f32(qvel[i]) for i in range(n)]; oa = [np.zeros(4) for _ in range(n)]
+    zero = torch.zeros((n, 4), device="cuda")
+    touched = np.zeros(n, dtype=bool)
+    for t in range(steps):
+        env.step(zero)
+        for i in range(n):
+            oq[i], ov[i], oa[i], _, nc, fz = orc.step_floor(models[i], 0.001, 2, oq[i], ov[i], oa[i], np.zeros(4))
+            touched[i] |= fz > 0
+    gq, gv, _, _, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    dp, dv = np.abs(gq - np.array(oq)).max(axis=1), np.abs(gv - np.array(ov)).max(axis=1)
+    print("tilted landings: %d of %d touched the floor; median |dpos| %.1e, worst %.1e; worst |dvel| %.1e" % (touched.sum(), n, np.median(dp), dp.max(), dv.max()))
+    assert touched.sum() > n // 2
+    assert np.median(dp) < 5e-6 and dp.max() < 1e-4 and dv.max() < 2e-3         # measured: 2.5e-7 / 1.4e-6 m, 2.2e-5 m/s
+    for t in range(1500):
+        env.step(zero)
+    gq, gv, _, _, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(np.isfinite(gq)) and np.all(np.isfinite(gv))
+    assert gq[:, 2].min() > -5e-3 and gq[:, 2].max() < 0.2                      # on the floor, not through it
+    assert np.abs(gv).max() < 0.05                                              # at rest (critically damped contacts + friction)
+
+
+def test_floor_env_in_flight_equals_plain_env_and_error_paths(qd):
+    """away from the floor the contact path is a height test: same trajectory as the env without floor (another instantiation of
+    the kernel: compared to float32 rounding); the load model and the multi-step kernels refuse the floor with a message"""
+    n, L = 256, qd._lib
+    rng = np.random.default_rng(5)
+    raw = rand_raw(rng, n, False)
+    mk = lambda floor: (lambda c: (setattr(c, "floor_contact", floor), qd.dev.DeviceEnv(c))[1])(
+        make_cfg(L, n, load=False, obs="BaseDroneEnv", reward="default_reward_fcn", frame_skip=1, h=0.01, max_steps=10 ** 6, max_distance=1e9))
+    a, b = mk(1), mk(0)
+    qpos = np.zeros((n, 7)); qpos[:, 3] = 1; qpos[:, 2] = 5.0
+    for e in (a, b):
+        e.set_params(raw); e.set_state(qpos, np.zeros((n, 6)), np.zeros((n, 4)))
+    act = torch.tensor(rng.uniform(0.3, 0.8, (n, 4)).astype(np.float32), device="cuda")
+    for _ in range(50):
+        oa_, _, _ = a.step(act); ob_, _, _ = b.step(act)
+    np.testing.assert_allclose(oa_.cpu().numpy(), ob_.cpu().numpy(), rtol=1e-5, atol=1e-5)
+    c = make_cfg(L, 8, load=True)
+    c.floor_contact = 1
+    with pytest.raises(NotImplementedError, match="single-body"):
+        qd.dev.DeviceEnv(c)
+    with pytest.raises(NotImplementedError, match="multi-step"):
+        a.rollout(torch.zeros((4, n, 4), device="cuda"))
+
+
+def test_simple_drone_bystanders_rest_on_the_floor(qd):
+    """SimpleDrone with several drones: only drone 0 is placed at start_pos, the others stay at their spawn sites 0.15 m above the
+    floor (env_gen.py:116-124) and, rotors off, come to rest ON it with floor_contact=True -- without it they fall for ever"""
+    from mujoco_drone_amd.environments.SimpleDrone import SimpleDrone
+    on = SimpleDrone(num_drones=4, reference=[0, 0, 1], floor_contact=True)
+    off = SimpleDrone(num_drones=4, reference=[0, 0, 1])
+    on.reset(); off.reset()
+    zero = torch.zeros((4, 4), device="cuda")
+    for _ in range(600):
+        on.step_tensor(zero); off.step_tensor(zero)
+    z_on, z_off = on.data.qpos.reshape(4, 7)[:, 2], off.data.qpos.reshape(4, 7)[:, 2]
+    assert np.all(np.abs(z_on - 0.01655) < 5e-4), z_on
+    assert np.all(z_off < -2.0), z_off

@@ -190,3 +190,69 @@ def test_pid_header_vs_reference_controllers(twin, golden, prec, tol):
             np.testing.assert_allclose(ct, G["pid_ctrl"][t][d], rtol=0, atol=tol * 50)
             np.testing.assert_allclose(ac, np.clip(G["pid_ctrl"][t][d] - 0.1, 0, 1), rtol=0, atol=tol * 50)
         assert st[12] == 0
+
+
+# ------------------------------------------------------------------ floor contact, single-body model
+def _rand_pose_near_floor(rng):
+    q = rng.normal(size=4); q /= np.linalg.norm(q)
+    if rng.uniform() < 0.5:                                  # nearly level, as when landing
+        ang = rng.normal(scale=0.15, size=3)
+        q = np.array([1.0, *(0.5 * ang)]); q /= np.linalg.norm(q)
+    return np.array([rng.normal(scale=0.3), rng.normal(scale=0.3), rng.uniform(-0.01, 0.12), *q])
+
+
+def test_floor_contact_generation_twin_vs_oracle(twin, orc):
+    """the product's contact generation (qd_contact.h) and the oracle's list the same contact points for random poses near the
+    floor: boxes, upright and tilted cylinders, any attitude"""
+    rng = np.random.default_rng(21)
+    twin.twin_floor_contacts.restype = C.c_int
+    twin.twin_floor_contacts.argtypes = [C.c_double, dp, dp]
+    seen = 0
+    for _ in range(400):
+        raw = rand_raw(rng, False)
+        m = orc.build_model(raw)
+        qpos = _rand_pose_near_floor(rng)
+        want = orc.floor_contacts(m, qpos)
+        out = np.zeros(4 * 64)
+        n = twin.twin_floor_contacts(float(raw[1]), P(qpos), P(out))
+        assert n == len(want)
+        got = out[:4 * n].reshape(n, 4)
+        for g, (pos, dist, body) in zip(got, want):
+            np.testing.assert_allclose(g[:3], pos, atol=1e-12)
+            assert abs(g[3] - dist) < 1e-12 and body == 0
+        seen += n
+    assert seen > 1000
+
+
+def test_floor_contact_solve_twin_vs_oracle(twin, orc):
+    """two routes to the minimiser of the same convex contact problem: the product's Newton method on the primal (6 unknowns,
+    COM coordinates, diagonal inertia) against the oracle's projected Gauss-Seidel on the dual (general Jacobians, full mass
+    matrix): accelerations and normal force agree for random poses / velocities in contact"""
+    rng = np.random.default_rng(22)
+    twin.twin_forward_floor.restype = C.c_int
+    twin.twin_forward_floor.argtypes = [dp, C.c_double, dp, dp, dp, C.c_double, dp, dp]
+    checked = 0
+    worst = 0.0
+    for _ in range(300):
+        raw = rand_raw(rng, False)
+        m = orc.build_model(raw)
+        m16 = np.zeros(32)
+        twin.twin_derive(P(np.asarray(raw, dtype=np.float64)), P(m16))
+        qpos = _rand_pose_near_floor(rng)
+        qvel = np.concatenate([rng.normal(scale=0.5, size=3), rng.normal(scale=1.0, size=3)])
+        act = rng.uniform(0, 1, 4)
+        h = float(rng.choice([0.01, 0.001]))
+        want, n_o, fz_o = orc.forward_floor(m, qpos, qvel, act, h)
+        got, fz = np.zeros(6), np.zeros(1)
+        n = twin.twin_forward_floor(P(m16), float(raw[1]), P(qpos), P(qvel), P(act), h, P(got), P(fz))
+        assert n == n_o
+        if fz_o > 0:
+            checked += 1
+            scale = max(1.0, float(np.abs(want).max()))
+            worst = max(worst, float(np.abs(got - want).max()) / scale)
+            np.testing.assert_allclose(got, want, rtol=2e-5, atol=2e-5 * scale)
+            assert abs(fz[0] - fz_o) < 2e-5 * max(1.0, fz_o)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
+    assert checked > 100
+    print("floor contact: %d states in contact, worst relative difference %.2e" % (checked, worst))

@@ -152,3 +152,79 @@ def test_hanging_load_small_oscillation_matches_damped_pendulum(orc, axis):
     decrement = np.mean(np.log(np.array(peaks[:-1]) / np.array(peaks[1:])))
     assert abs(decrement - c / (2 * I) * 2 * np.pi / wd) / decrement < 2e-2
     assert abs(qpos[2] - 15) < 1e-3 and np.abs(qpos[:2]).max() < 5e-3     # the heavy drone stays put (mm of drift from the first swing)
+
+
+# ------------------------------------------------------------------ floor contact: analytic anchors
+def test_floor_rest_force_equals_weight_and_settles_critically_damped(orc):
+    """a drone dropped from 3 cm with the rotors off lands on the four lower corners of its core box; at rest the normal force is
+    the weight (to the solver tolerance), the penetration is sub-millimetre, and the approach to rest after the impact has
+    MuJoCo's default constraint time constant: solref (0.02, 1) = critically damped, z - z_rest ~ (a + b t) exp(-t / 0.02 / dmax')"""
+    m = _model(orc, 0)
+    qpos = np.array([0.3, -0.2, 0.0166667 + 0.03, 1, 0, 0, 0.0]); qvel = np.zeros(6); act = np.zeros(4)
+    zs, fs, ns = [], [], []
+    for k in range(600):
+        qpos, qvel, act, sens, n, fz = orc.step_floor(m, 0.001, 1, qpos, qvel, act, np.zeros(4))
+        zs.append(qpos[2]); fs.append(fz); ns.append(n)
+    w = m.m0 * m.gravity
+    assert ns[-1] == 4 and abs(fs[-1] - w) < 1e-3 * w
+    pen = 0.016667 - zs[-1]
+    assert 0 < pen < 5e-4                                            # stiff: fractions of a millimetre
+    assert abs(qvel).max() < 1e-4 and abs(qpos[0] - 0.3) < 1e-6 and abs(qpos[1] + 0.2) < 1e-6
+    # accelerometer at rest on the floor reads +g along body z (specific force)
+    np.testing.assert_allclose(sens, [0, 0, m.gravity], atol=2e-3)
+    # after the first rebound the height error decays monotonically (no oscillation: damping ratio 1)
+    tail = np.array(zs[200:]) - zs[-1]
+    assert np.all(np.diff(np.abs(tail)) <= 1e-9)
+
+
+def test_floor_friction_is_coulomb_with_mu_one(orc):
+    """sliding on the floor: a level drone given a horizontal velocity decelerates at nearly mu g = g until it sticks (pyramidal cone,
+    friction 1 from max(geom friction 1, floor friction 1)); a slow push below the cone limit does not move it"""
+    m = _model(orc, 0)
+    qpos = np.array([0, 0, 0.01655, 1, 0, 0, 0.0]); qvel = np.zeros(6); act = np.zeros(4)
+    for _ in range(300):
+        qpos, qvel, act, _, _, _ = orc.step_floor(m, 0.001, 1, qpos, qvel, act, np.zeros(4))
+    qvel[0] = 1.0                                                    # 1 m/s along x
+    v = []
+    for _ in range(60):
+        qpos, qvel, act, _, n, fz = orc.step_floor(m, 0.001, 1, qpos, qvel, act, np.zeros(4))
+        v.append(qvel[0])
+    dec = -(v[50] - v[10]) / 0.040
+    # an elliptic cone would give exactly mu g; in the pyramidal cone the two edges across the sliding direction keep carrying part
+    # of the normal load without contributing friction, so the deceleration sits a little below g (9.07 m/s^2 with these constants)
+    assert 0.88 * m.gravity < dec < 1.0 * m.gravity, dec
+    for _ in range(400):
+        qpos, qvel, act, _, _, _ = orc.step_floor(m, 0.001, 1, qpos, qvel, act, np.zeros(4))
+    assert abs(qvel[:3]).max() < 1e-3                                # stuck
+
+
+def test_floor_is_inactive_in_flight(orc):
+    """above the floor the step with contact IS the step without (no geom below z = 0): bit-identical states"""
+    rng = np.random.default_rng(8)
+    for load in (0, 1):
+        m = _model(orc, load)
+        nq, nv = (9, 8) if load else (7, 6)
+        qpos = np.zeros(nq); qpos[:3] = [0, 0, 3.0]; q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q)
+        qvel = rng.normal(size=nv); act = rng.uniform(0, 1, 4); ctrl = rng.uniform(0, 1, 4)
+        a = orc.step(m, 0.01, 3, qpos, qvel, act, ctrl)
+        b = orc.step_floor(m, 0.01, 3, qpos, qvel, act, ctrl)
+        for x, y in zip(a, b[:4]):
+            np.testing.assert_array_equal(x, y)
+        assert b[4] == 0
+
+
+def test_floor_contact_of_the_hanging_load(orc):
+    """load model: the 1.2 m tether lets the load box reach the floor while the drone hovers at 1 m: the box rests on the floor
+    (contacts on body 2), the tether goes slack-free (rigid rod) and the normal force carries part of the weight"""
+    m = _model(orc, 1)
+    mt = m.m0 + m.m1 + m.m2
+    qpos = np.array([0, 0, 1.0, 1, 0, 0, 0, 0.3, 0.0]); qvel = np.zeros(8)
+    hover = mt * m.gravity / (4 * m.gearF)
+    act = np.full(4, hover)
+    seen = 0
+    for k in range(400):
+        qpos, qvel, act, sens, n, fz = orc.step_floor(m, 0.002, 1, qpos, qvel, act, np.full(4, hover))
+        seen = max(seen, n)
+        assert np.all(np.isfinite(qpos)) and fz >= 0
+    cons = orc.floor_contacts(m, qpos)
+    assert seen > 0 and all(b == 2 for _, _, b in cons)
