@@ -392,9 +392,10 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
   if constexpr (SPEC == SPEC_FLOOR) {
-    static_assert(!LOAD, "floor contact is built for the single-body model");
-    const double arm_len = a.raw[(size_t)1 * a.npad + i];  // float64 raw parameter plane: the geom sizes are %.5g-rounded from it
-    for (int k = 0; k < a.frame_skip; k++) e.acc = substep_floor<float>(e.M, e.s, c0, c1, c2, c3, a.h, arm_len);
+    // float64 raw parameter planes: the geom sizes are %.5g-rounded from them
+    const double arm_len = a.raw[(size_t)1 * a.npad + i], pend_len = LOAD ? a.raw[(size_t)4 * a.npad + i] : 0.0,
+                 weight_mass = LOAD ? a.raw[(size_t)5 * a.npad + i] : 0.0;
+    for (int k = 0; k < a.frame_skip; k++) e.acc = substep_floor<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h, arm_len, pend_len, weight_mass);
   } else if (spec_frame_skip<SPEC>() == 1) {
     e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
   } else if (spec_frame_skip<SPEC>() == 2) {
@@ -1149,7 +1150,6 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   e->regen = 0;
   e->spec = SPEC_GENERIC;
   if (c->floor_contact) {
-    if (e->load) { delete e; return fail(QD_ERR_UNSUPPORTED, "floor contact is built for the single-body model (no hanging load)"); }
     e->spec = SPEC_FLOOR;
   } else if (e->load && c->obs_kind == QD_OBS_RPY_PARAMS && c->reward_kind == QD_REW_DISTANCE_ENERGY && c->ctrl_map == QD_CTRL_AFFINE &&
       c->term_kind == QD_TERM_DEFAULT && c->frame_skip == 1)
@@ -1307,6 +1307,7 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
       if (env->spec == SPEC_RMA) QD_STEP_LAUNCH(true, BLK, SPEC_RMA);        \
       else if (env->spec == SPEC_LSTM) QD_STEP_LAUNCH(true, BLK, SPEC_LSTM); \
       else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC_FS1); \
+      else if (env->spec == SPEC_FLOOR) QD_STEP_LAUNCH(true, BLK, SPEC_FLOOR); \
       else QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC);                          \
     } else {                                                                 \
       if (env->spec == SPEC_SIMPLE) QD_STEP_LAUNCH(false, BLK, SPEC_SIMPLE); \

@@ -13,7 +13,7 @@ Differences a user can observe (all listed in DESIGN.md):
     sequential numpy PCG64 stream, so sampled states/params differ draw-for-draw while the
     draw -> value transforms are identical;
   * arithmetic is float32 on the device (the reference is float64);
-  * the floor (env_gen.py:97) is off unless config['floor_contact'] is set (single-body model only; the training
+  * the floor (env_gen.py:97) is off unless config['floor_contact'] is set (the training
     configs fly at z = 15 m and truncate at 4 m from the reference point, so they never reach it).
 """
 import types
@@ -134,7 +134,7 @@ class BaseDroneEnv(_VectorEnvBase):
         # --- extensions (keys the reference does not have) ------------------------------
         self.device = config.get('device', 'cuda:0')
         self.auto_reset = bool(config.get('auto_reset', False))
-        # the floor plane of env_gen.py:97 as a soft contact (single-body model only; SURVEY 8f-1, parity unpinned): off by default,
+        # the floor plane of env_gen.py:97 as a soft contact (parity unpinned): off by default,
         # the training configurations fly at z = 15 m and are truncated 4 m from the reference
         self.floor_contact = bool(config.get('floor_contact', False))
         self.per_env_reference = bool(config.get('per_env_reference', False))

@@ -182,4 +182,24 @@ int twin_forward_floor(const double* model16, double arm_len, const double* qpos
   qacc[0] = ex.lin.x; qacc[1] = ex.lin.y; qacc[2] = ex.lin.z; qacc[3] = ex.ang.x; qacc[4] = ex.ang.y; qacc[5] = ex.ang.z;
   return n;
 }
+// qacc (8) of the load model including the floor's reaction, explicit (qacc) and damping-implicit (qimp); returns the contacts
+int twin_forward_floor_tree(const double* model16, const double* raw, const double* qpos, const double* qvel, const double* act, double h,
+                            double* qacc, double* qimp, double* force_z) {
+  Model<double> M;
+  double* mp = reinterpret_cast<double*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = model16[i];
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = qpos[7]; s.th2 = qpos[8];
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5]; s.thd1 = qvel[6]; s.thd2 = qvel[7];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  Accel<double> ex, im;
+  V3<double> acc;
+  forward<double, true>(M, s, h, &ex, &im, &acc);
+  const int n = floor_contact_tree<double>(M, s, raw[1], raw[4], raw[5], h, ex, im, force_z);
+  const double a[8] = {ex.lin.x, ex.lin.y, ex.lin.z, ex.ang.x, ex.ang.y, ex.ang.z, ex.thdd1, ex.thdd2};
+  const double b[8] = {im.lin.x, im.lin.y, im.lin.z, im.ang.x, im.ang.y, im.ang.z, im.thdd1, im.thdd2};
+  for (int i = 0; i < 8; i++) { qacc[i] = a[i]; qimp[i] = b[i]; }
+  return n;
+}
 }

@@ -115,7 +115,7 @@ def test_tilted_landings_with_velocity_vs_oracle(qd, orc):
 
 def test_floor_env_in_flight_equals_plain_env_and_error_paths(qd):
     """away from the floor the contact path is a height test: same trajectory as the env without floor (another instantiation of
-    the kernel: compared to float32 rounding); the load model and the multi-step kernels refuse the floor with a message"""
+    the kernel: compared to float32 rounding); the multi-step kernels refuse the floor with a message"""
     n, L = 256, qd._lib
     rng = np.random.default_rng(5)
     raw = rand_raw(rng, n, False)
@@ -129,10 +129,6 @@ def test_floor_env_in_flight_equals_plain_env_and_error_paths(qd):
     for _ in range(50):
         oa_, _, _ = a.step(act); ob_, _, _ = b.step(act)
     np.testing.assert_allclose(oa_.cpu().numpy(), ob_.cpu().numpy(), rtol=1e-5, atol=1e-5)
-    c = make_cfg(L, 8, load=True)
-    c.floor_contact = 1
-    with pytest.raises(NotImplementedError, match="single-body"):
-        qd.dev.DeviceEnv(c)
     with pytest.raises(NotImplementedError, match="multi-step"):
         a.rollout(torch.zeros((4, n, 4), device="cuda"))
 
@@ -150,3 +146,46 @@ def test_simple_drone_bystanders_rest_on_the_floor(qd):
     z_on, z_off = on.data.qpos.reshape(4, 7)[:, 2], off.data.qpos.reshape(4, 7)[:, 2]
     assert np.all(np.abs(z_on - 0.01655) < 5e-4), z_on
     assert np.all(z_off < -2.0), z_off
+
+
+def test_load_touchdown_vs_oracle(qd, orc):
+    """the load model (drone + tether + load box): descending with a little less than hover thrust until the hanging box lands,
+    the tether leans over and the airframe follows; contacts on the box, the rod and the airframe, 8 generalised coordinates with
+    the hinge damping implicit; trajectory against the oracle, then rest"""
+    n, steps, h = 48, 250, 0.004
+    rng = np.random.default_rng(6)
+    raw = rand_raw(rng, n, True)
+    c = make_cfg(qd._lib, n, load=True, obs="BaseDroneEnv", reward="default_reward_fcn", frame_skip=1, h=h, ctrl_map=0,
+                 max_steps=10 ** 6, max_distance=1e9, ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0))
+    c.floor_contact = 1
+    env = qd.dev.DeviceEnv(c)
+    env.set_params(raw)
+    qpos = np.zeros((n, 9)); qpos[:, 3] = 1
+    qpos[:, 0:2] = rng.normal(scale=0.3, size=(n, 2))
+    qpos[:, 2] = raw[:, 4] + 0.1 * np.cbrt(raw[:, 5]) + rng.uniform(0.02, 0.15, n)       # the box a few cm above the floor
+    qpos[:, 7:] = rng.normal(scale=0.08, size=(n, 2))
+    qvel = np.zeros((n, 8)); qvel[:, 2] = -rng.uniform(0.1, 0.5, n); qvel[:, 6:] = rng.normal(scale=0.3, size=(n, 2))
+    models = [orc.build_model(r) for r in raw]
+    hover = np.array([(m.m0 + m.m1 + m.m2) * 9.81 / (4 * m.gearF) for m in models])
+    act = np.tile((0.8 * hover)[:, None], (1, 4))
+    env.set_state(qpos, qvel, act)
+    f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    oq = [f32(qpos[i]) for i in range(n)]; ov = [f32(qvel[i]) for i in range(n)]; oa = [f32(act[i]) for i in range(n)]
+    ctrl = torch.tensor(act.astype(np.float32), device="cuda")
+    touched = np.zeros(n, dtype=bool)
+    bodies = set()
+    for t in range(steps):
+        env.step(ctrl)
+        for i in range(n):
+            oq[i], ov[i], oa[i], _, nc, fz = orc.step_floor(models[i], h, 1, oq[i], ov[i], oa[i], f32(act[i]))
+            touched[i] |= fz > 0
+        if t == steps // 2:
+            for i in range(n):
+                bodies |= {b for _, d, b in orc.floor_contacts(models[i], oq[i]) if d < 0}
+    gq, gv, _, _, _ = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    dp, dv = np.abs(gq - np.array(oq)).max(axis=1), np.abs(gv - np.array(ov)).max(axis=1)
+    print("load touchdown: %d of %d touched; bodies in contact %s; median |dq| %.1e, worst %.1e; worst |dv| %.1e"
+          % (touched.sum(), n, sorted(bodies), np.median(dp), dp.max(), dv.max()))
+    assert touched.all() and 2 in bodies
+    assert np.median(dp) < 5e-6 and dp.max() < 1e-4 and dv.max() < 1e-3          # measured: 2.9e-7 / 3.9e-6, 8.1e-6
+    assert np.all(np.isfinite(gq)) and gq[:, 2].min() > -5e-3

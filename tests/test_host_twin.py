@@ -256,3 +256,43 @@ def test_floor_contact_solve_twin_vs_oracle(twin, orc):
             np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-9)
     assert checked > 100
     print("floor contact: %d states in contact, worst relative difference %.2e" % (checked, worst))
+
+
+def test_floor_contact_tree_twin_vs_oracle(twin, orc):
+    """the load model: drone + tether + load box near the floor (the box, the rod or the airframe touching), the product's 8-unknown
+    Newton method with its own mass-matrix assembly against the oracle's dual solver: constrained accelerations and normal force"""
+    rng = np.random.default_rng(23)
+    twin.twin_forward_floor_tree.restype = C.c_int
+    twin.twin_forward_floor_tree.argtypes = [dp, dp, dp, dp, dp, C.c_double, dp, dp, dp]
+    checked, worst = 0, 0.0
+    for trial in range(300):
+        raw = np.asarray(rand_raw(rng, True), dtype=np.float64)
+        m = orc.build_model(raw)
+        m16 = np.zeros(32)
+        twin.twin_derive(P(raw), P(m16))
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        if trial % 2:
+            ang = rng.normal(scale=0.2, size=3); q = np.array([1.0, *(0.5 * ang)]); q /= np.linalg.norm(q)
+        z = rng.uniform(0.0, 0.3) if trial % 3 == 0 else raw[4] + rng.uniform(-0.15, 0.25)     # airframe low, or the load near the floor
+        qpos = np.array([rng.normal(scale=0.3), rng.normal(scale=0.3), z, *q, rng.normal(scale=0.4), rng.normal(scale=0.4)])
+        qvel = np.concatenate([rng.normal(scale=0.5, size=3), rng.normal(scale=1.0, size=3), rng.normal(scale=1.0, size=2)])
+        act = rng.uniform(0, 1, 4)
+        h = float(rng.choice([0.01, 0.002]))
+        want, n_o, fz_o = orc.forward_floor(m, qpos, qvel, act, h)
+        got, gimp, fz = np.zeros(8), np.zeros(8), np.zeros(1)
+        n = twin.twin_forward_floor_tree(P(m16), P(raw), P(qpos), P(qvel), P(act), h, P(got), P(gimp), P(fz))
+        assert n == n_o, (trial, n, n_o)
+        scale = max(1.0, float(np.abs(want).max()))
+        if fz_o > 0:
+            checked += 1
+            worst = max(worst, float(np.abs(got - want).max()) / scale)
+            np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-6 * scale)
+            assert abs(fz[0] - fz_o) < 1e-6 * max(1.0, fz_o)
+            # the Euler step's accelerations: (M + h D) qimp = M qacc, checked through the oracle's mass matrix
+            Mm = orc.mass_matrix(m, qpos)
+            Mh = Mm.copy(); Mh[6, 6] += h * 0.15; Mh[7, 7] += h * 0.15
+            np.testing.assert_allclose(gimp, np.linalg.solve(Mh, Mm @ want), rtol=1e-6, atol=1e-6 * scale)
+        else:
+            np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8 * scale)
+    assert checked > 100
+    print("floor contact (load model): %d states in contact, worst relative difference %.2e" % (checked, worst))
