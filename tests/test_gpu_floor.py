@@ -189,3 +189,32 @@ def test_load_touchdown_vs_oracle(qd, orc):
     assert touched.all() and 2 in bodies
     assert np.median(dp) < 5e-6 and dp.max() < 1e-4 and dv.max() < 1e-3          # measured: 2.9e-7 / 3.9e-6, 8.1e-6
     assert np.all(np.isfinite(gq)) and gq[:, 2].min() > -5e-3
+
+
+def test_take_off_and_landing_through_the_python_surface(qd):
+    """config key `floor_contact` on the mirror classes: drones start ON the floor (rotors off: they stay put), the reference's
+    analytic PID cascade takes them off towards a waypoint 3 m up (it settles about 1.5 m below its reference, DESIGN section 4: a
+    waypoint at 1 m would keep them grounded), then the rotors are cut and they land and come to rest"""
+    from mujoco_drone_amd.environments.BaseDroneEnv import BaseDroneEnv, base_config
+    n = 32
+    cfg = dict(base_config, num_drones=n, pendulum=False, floor_contact=True, reference=[0, 0, 3.0, 0], start_pos=[0, 0, 0.0167, 0],
+               random_start_pos=False, random_params=True, param_difficulty=1, max_steps=10 ** 6, max_distance=1e9)
+    env = BaseDroneEnv(cfg)
+    env.vector_reset_tensor()
+    zero = torch.zeros((n, 4), device="cuda")
+    for _ in range(100):
+        env.vector_step_tensor(zero)                           # ctrl = 0.1 + 0.9 * 0: a tenth of the rotor force, far below the weight
+    z = env.data.qpos.reshape(n, 7)[:, 2]
+    assert np.all(np.abs(z - 0.0166) < 6e-4), z                # resting on the core box
+    env.pid_reset()
+    zmax = np.zeros(n)
+    for _ in range(600):
+        env.vector_step_tensor(env.pid_action_tensor())
+        zmax = np.maximum(zmax, env._dev.get_state()[0][:, 2].cpu().numpy())
+    assert np.all(zmax > 0.5), zmax.min()                      # airborne
+    for _ in range(500):
+        env.vector_step_tensor(zero)
+    q, v = env._dev.get_state()[0].cpu().numpy(), env._dev.get_state()[1].cpu().numpy()
+    assert np.all(q[:, 2] < 0.2) and np.all(q[:, 2] > -1e-3) and np.abs(v).max() < 0.3 and np.all(np.isfinite(q))
+    with pytest.raises(NotImplementedError, match="multi-step"):
+        env.rollout_pid_tensor(8)
