@@ -18,6 +18,9 @@
 #pragma once
 #include "qd_dynamics.h"
 
+// the contact solve is a real call on the device: its registers and scratch are then allocated apart from the flight path's
+#define QD_NOINLINE __attribute__((noinline))
+
 namespace qd {
 
 constexpr int CONTACT_MAX = 40;  // 14 geoms: at most 6 boxes x 4 + 8 cylinders x 4 = 56; more than 40 at once needs the drone half buried
@@ -140,7 +143,7 @@ QD_HD void contact_solve6(double H[36], const double g[6], double dx[6]) {
 //   lin: world-frame acceleration of the body origin (qacc[0:3]), ang: body-frame angular acceleration (qacc[3:6])
 // Returns the number of contacts; *force_z the total normal force.
 template <class T>
-QD_HD int floor_contact(const Model<T>& M, const State<T>& s, double arm_len, double h, V3<T>& lin, V3<T>& ang, double* force_z) {
+QD_HD QD_NOINLINE int floor_contact(const Model<T>& M, const State<T>& s, double arm_len, double h, V3<T>& lin, V3<T>& ang, double* force_z) {
   if (force_z) *force_z = 0.0;
   // cheap exit: nothing of the drone reaches further than arm + propeller radius from the origin
   const double reach = 1.4142135623730951 * 0.05 + arm_len * (1.0 + 1.0 / 1.5) + 0.03;
@@ -362,7 +365,7 @@ QD_HD void tree_chol_solve(const double L[64], const double b[8], double x[8]) {
 // Adds the floor's reaction to the accelerations of the load model: `ex` (explicit, what the accelerometer sees) and `im` (with
 // the hinge damping implicit, what the Euler step uses: (M + h D) qimp = M qacc like MuJoCo's Euler integrator).
 template <class T>
-QD_HD int floor_contact_tree(const Model<T>& M, const State<T>& s, double arm_len, double pend_len, double weight_mass, double h,
+QD_HD QD_NOINLINE int floor_contact_tree(const Model<T>& M, const State<T>& s, double arm_len, double pend_len, double weight_mass, double h,
                              Accel<T>& ex, Accel<T>& im, double* force_z) {
   if (force_z) *force_z = 0.0;
   const double bs = round5(0.1 * cbrt(weight_mass));

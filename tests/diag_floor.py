@@ -1,0 +1,35 @@
+"""diagnostic (not a test): cost of the floor-contact step kernels at 4096 envs -- in flight (height test only) and with every env
+resting on the floor (contact generation + Newton solve in every lane)"""
+import os, sys
+import numpy as np
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from mujoco_drone_amd import _lib as L
+from mujoco_drone_amd.environments import _device as dev
+from test_gpu_parity import make_cfg, rand_raw
+n = 4096
+rng = np.random.default_rng(0)
+for load in (False, True):
+    for where in ("flight", "floor"):
+        c = make_cfg(L, n, load=load, obs="BaseDroneEnv", reward="default_reward_fcn", frame_skip=1, h=0.002, ctrl_map=0, max_steps=10 ** 7, max_distance=1e9)
+        c.floor_contact = 1
+        env = dev.DeviceEnv(c)
+        raw = rand_raw(rng, n, load)
+        env.set_params(raw)
+        nq, nv = (9, 8) if load else (7, 6)
+        qpos = np.zeros((n, nq)); qpos[:, 3] = 1
+        qpos[:, 2] = 50.0 if where == "flight" else (0.02 if not load else 0.3)
+        if load and where == "floor":
+            qpos[:, 7] = 1.2                      # tether swung aside so that the box lies on the floor next to the airframe's height
+        env.set_state(qpos, np.zeros((n, nv)), np.zeros((n, 4)))
+        a = torch.zeros((n, 4), device="cuda")
+        for _ in range(300):
+            env.step(a)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200):
+            env.step(a)
+        e1.record(); torch.cuda.synchronize()
+        z = env.get_state()[0][:, 2]
+        print("%-8s %-6s: %.1f us per step of %d envs (z mean %.3f)" % ("load" if load else "no load", where, e0.elapsed_time(e1) * 1000 / 200, n, float(z.mean())), flush=True)
