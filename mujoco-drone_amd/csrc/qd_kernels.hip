@@ -1367,7 +1367,6 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
 
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
   QD_NEED(env);
-  if (env->spec == SPEC_FLOOR) return fail(QD_ERR_UNSUPPORTED, "multi-step kernels do not carry the floor contact: step with qd_step / qd_step_fragment");
   const KArgs& k = env->ka;
   if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
   if (T == 0) return QD_OK;
@@ -1378,10 +1377,12 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
     if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
     else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
+    else if (env->spec == SPEC_FLOOR) QD_ROLL(true, SPEC_FLOOR);
     else QD_ROLL(true, SPEC_GENERIC);
   } else {
     if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
+    else if (env->spec == SPEC_FLOOR) QD_ROLL(false, SPEC_FLOOR);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL
@@ -1409,7 +1410,6 @@ int qd_pid_action(qd_env* env, float* actions, void* stream) {
 
 int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out, void* stream) {
   QD_NEED(env);
-  if (env->spec == SPEC_FLOOR) return fail(QD_ERR_UNSUPPORTED, "multi-step kernels do not carry the floor contact: step with qd_step / qd_step_fragment");
   const KArgs& k = env->ka;
   if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
   if (T == 0) return QD_OK;
@@ -1421,9 +1421,11 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
     if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
     else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
+    else if (env->spec == SPEC_FLOOR) QD_ROLL(true, SPEC_FLOOR);
     else QD_ROLL(true, SPEC_GENERIC);
   } else {
     if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
+    else if (env->spec == SPEC_FLOOR) QD_ROLL(false, SPEC_FLOOR);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL
