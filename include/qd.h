@@ -101,9 +101,10 @@ typedef struct qd_config {
    *   dt = frame_skip * timestep; the step taken from episode step k is rewarded against ref_i(k). */
   int32_t  ref_mode;            /* QD_REF_* */
   int32_t  floor_contact;       /* extension switch for SURVEY 8f-1: 0 = no floor (the BASELINE configurations never reach it: flight at
-                                 * z = 15 m, truncation at 4 m); 1 = the drone's 14 geoms collide with the floor plane z = 0
-                                 * (env_gen.py:97) in the manner of MuJoCo's soft contacts: pyramidal friction cone, mu = 1, default
-                                 * solref / solimp; with the load also the link sphere, the tether rod and the load box.    PARITY UNPINNED beyond the rest of the physics: see DESIGN.md section 8. */
+                                 * z = 15 m, truncation at 4 m); 1 = the drone's geoms -- the airframe's 14, with the load also the link
+                                 * sphere, the tether rod and the load box -- collide with the floor plane z = 0 (env_gen.py:97) in the
+                                 * manner of MuJoCo's soft contacts: pyramidal friction cone, mu = 1, default solref / solimp.
+                                 * PARITY UNPINNED beyond the rest of the physics: see DESIGN.md section 4 ("Floor contact"). */
   double   ref_radius, ref_frequency;
   /* QD_REF_STEP / QD_REF_RAMP: gen_step_trajectory / gen_ramp_trajectory (evaluation.py:141-152) with
    * start_pos = `reference`, end_pos = ref_end, sampled once per env step at t_k = k dt like the reference's
