@@ -299,6 +299,47 @@ def test_step_outputs_vs_oracle(qd, orc, obs, reward, load):
     assert tr.all()  # max_steps = 3 reached
 
 
+@pytest.mark.parametrize("load", [True, False])
+def test_every_observation_reward_combination_vs_oracle(qd, orc, load):
+    """the whole grid: 13 observation variants x 17 reward functions (x the SimpleDrone pair) on the fused step, two steps each on
+    random states, against the oracle -- so that no (variant, reward) pair depends on a dispatch path only the training
+    configurations exercise"""
+    L = qd._lib
+    rng = np.random.default_rng(33 + load)
+    n = 48
+    raw = rand_raw(rng, n, load)
+    ref = (0.2, -0.1, 15.0, 0.4)
+    combos, refused = 0, set()
+    for obs in L.OBS_KINDS:
+        if obs in ("LocalFramePRYaccParamsNoPendEnv", "SimpleDrone"):       # the variant that raises in the reference; SimpleDrone is its own class
+            continue
+        for reward in L.REWARD_KINDS:
+            if reward == "simple_drone_reward":
+                continue
+            qpos, qvel, act = rand_state(rng, n, load)
+            qpos[:, :3] = np.array([0, 0, 15]) + rng.normal(scale=1.5, size=(n, 3))
+            try:
+                env = qd.dev.DeviceEnv(make_cfg(L, n, load=load, obs=obs, reward=reward, ref=ref, max_steps=50))
+            except NotImplementedError as ex:       # rewards that index past the 29-element no-load state: IndexError in the reference
+                assert not load and "29-element" in str(ex), (obs, reward, str(ex))
+                refused.add(reward)
+                continue
+            env.set_params(raw)
+            env.set_state(qpos, qvel, act)
+            ob = orc.Batch(raw, load, L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(reward), 0.01, 1, 1, ref, 4.0, 50)
+            ob.qpos[:], ob.qvel[:], ob.act[:] = (qpos.astype(np.float32), qvel.astype(np.float32), act.astype(np.float32))
+            for t in range(2):
+                a = rng.uniform(0, 1, (n, 4)).astype(np.float32)
+                o, r, tr = env.step(a)
+                oo, orr, otr = ob.step(a.astype(np.float64))
+                o, r = o.cpu().numpy(), r.cpu().numpy()
+                assert o.shape == oo.shape, (obs, reward)
+                np.testing.assert_allclose(o, oo, rtol=1e-4, atol=3e-3, err_msg="%s / %s" % (obs, reward))
+                np.testing.assert_allclose(r, orr, rtol=3e-4, atol=3e-3, err_msg="%s / %s" % (obs, reward))
+            combos += 1
+    assert combos == 14 * (17 - len(refused)) and (len(refused) > 0) == (not load), (combos, refused)
+
+
 # ------------------------------------------------------------------ reset sampling / parameter randomisation
 @pytest.mark.parametrize("load", [True, False])
 def test_reset_sampling_vs_oracle(qd, orc, load):
