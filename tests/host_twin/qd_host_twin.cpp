@@ -202,4 +202,13 @@ int twin_forward_floor_tree(const double* model16, const double* raw, const doub
   for (int i = 0; i < 8; i++) { qacc[i] = a[i]; qimp[i] = b[i]; }
   return n;
 }
+// the 8 x 8 mass matrix the contact path assembles from the three bodies' COM Jacobians (row-major)
+void twin_tree_mass_matrix(const double* model16, const double* qpos, double* out64) {
+  Model<double> M;
+  double* mp = reinterpret_cast<double*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = model16[i];
+  TreePose P;
+  tree_pose(qpos, qpos + 3, qpos[7], qpos[8], P);
+  tree_mass_matrix(M, P, out64);
+}
 }

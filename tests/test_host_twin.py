@@ -296,3 +296,22 @@ def test_floor_contact_tree_twin_vs_oracle(twin, orc):
             np.testing.assert_allclose(got, want, rtol=1e-8, atol=1e-8 * scale)
     assert checked > 100
     print("floor contact (load model): %d states in contact, worst relative difference %.2e" % (checked, worst))
+
+
+def test_three_assemblies_of_the_mass_matrix_agree(twin, orc):
+    """the load model's 8 x 8 mass matrix exists three times, written independently: the oracle's projected Newton-Euler assembly,
+    the product's contact path (COM Jacobians of the three bodies, qd_contact.h) and -- implicitly, never formed -- the body-frame
+    elimination of qd_dynamics.h (checked through accelerations elsewhere).  The two explicit ones must agree to rounding"""
+    rng = np.random.default_rng(24)
+    twin.twin_tree_mass_matrix.argtypes = [dp, dp, dp]
+    for _ in range(50):
+        raw = np.asarray(rand_raw(rng, True), dtype=np.float64)
+        m = orc.build_model(raw)
+        m16 = np.zeros(32)
+        twin.twin_derive(P(raw), P(m16))
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        qpos = np.array([*rng.normal(size=3), *q, rng.normal(scale=0.7), rng.normal(scale=0.7)])
+        got = np.zeros(64)
+        twin.twin_tree_mass_matrix(P(m16), P(qpos), P(got))
+        want = orc.mass_matrix(m, qpos)
+        np.testing.assert_allclose(got.reshape(8, 8), want, rtol=1e-9, atol=1e-11)
