@@ -1085,9 +1085,8 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   if (reinterpret_cast<uintptr_t>(arena) % 256 != 0) return fail(QD_ERR_ARENA, "arena must be 256-byte aligned");
   if (arena_bytes < qd_arena_bytes(c->num_envs))
     return fail(QD_ERR_ARENA, "arena has %zu bytes, need %zu", arena_bytes, qd_arena_bytes(c->num_envs));
-  qd_env* e = new (std::nothrow) qd_env;
+  qd_env* e = new (std::nothrow) qd_env();  // value-initialised: the plain members are zeroed, the vector and the graph slots default-constructed
   if (!e) return fail(QD_ERR_INVALID, "out of host memory");
-  memset(e, 0, sizeof *e);
   e->cfg = *c;
   e->load = c->model == QD_MODEL_LOAD;
   e->ns = qd_state_dim(c->model);
