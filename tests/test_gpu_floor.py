@@ -250,3 +250,30 @@ def test_rollout_kernel_with_floor_equals_steps(qd, load):
             # it: measured 6e-5 on single entries after 160 steps with impacts
             np.testing.assert_allclose(obs[t].cpu().numpy(), o2.cpu().numpy(), rtol=3e-4, atol=3e-4, err_msg="t=%d" % t)
     assert float(b.get_state()[0][:, 2].max()) < (2.0 if load else 0.2)      # they did come down
+
+
+def test_policy_rollout_on_a_floor_env():
+    """qd_rollout_policy on an env with the floor goes through its two-launch path (the fused kernel has no floor instantiation):
+    same trajectory as policy.forward + vector_step taken one by one, starting on the ground with a random-init actor"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from mujoco_drone_amd.policy import DevicePolicy, random_weights
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    n, T = 64, 120
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward, floor_contact=True, reference=[0, 0, 2.0, 0],
+               start_pos=[0, 0, 1.6, 0], random_start_pos=False, random_params=True, param_difficulty=1, max_steps=10 ** 6, max_distance=1e9)
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    pol = DevicePolicy("RMA_full", random_weights("RMA_full", 5))
+    o1 = e1.vector_reset_tensor().clone(); o2 = e2.vector_reset_tensor().clone()
+    assert torch.equal(o1, o2)
+    out = pol.rollout(e1._dev, T, o1)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a = pol.forward(obs, prev, tr)
+        ob, rw, trn = e2.vector_step_tensor(a)
+        obs, prev, tr = ob.clone(), a, trn.clone()
+        if t in (0, 30, T - 1):
+            np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), rtol=3e-4, atol=3e-4, err_msg="t=%d" % t)
+    assert bool(torch.isfinite(out["obs"]).all())
