@@ -301,6 +301,10 @@ class BaseDroneEnv(_VectorEnvBase):
     def close(self):
         return None
 
+    def viewer_setup(self):
+        """camera placement of the reference's viewer (rendering is out of scope): accepted and ignored"""
+        return None
+
     def get_drone_states(self):
         self._cache().pop('states', None)
         return self.states

@@ -109,3 +109,7 @@ class SimpleDrone:
 
     def close(self):
         return None
+
+    def viewer_setup(self):
+        """camera placement of the reference's viewer (rendering is out of scope): accepted and ignored"""
+        return None
