@@ -205,7 +205,7 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
     from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
     from mujoco_drone_amd.environments.rewards import distance_energy_reward
     monkeypatch.delenv("QD_POLICY_GENERIC", raising=False)
-    for tag, fam in TAGS.items():
+    for tag, fam in dict(TAGS, custom_mlp="CustomMLP", rma_smaller="RMA_model_smaller").items():   # every network with a fused instantiation
         pol = DevicePolicy(fam, weights_of(PG, tag))
         assert pol.kernel > 0
         cfg = dict(base_config, num_drones=203, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
