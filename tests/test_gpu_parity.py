@@ -957,3 +957,24 @@ def test_ragged_and_threshold_batch_sizes(qd, n):
     assert torch.isfinite(q).all() and torch.isfinite(v).all() and torch.isfinite(ob).all()
     assert int(k[0]) == int(k[-1]) == T % 7
     assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(n, device=q.device), atol=1e-5)
+
+
+def test_arena_is_the_whole_device_state(qd):
+    """checkpoint / resume: the caller-owned arena holds everything the step kernels carry (state, parameters, model constants,
+    episode counters, reset pool).  Copying it into a second env created from the same configuration and stepping both with the
+    same actions gives bit-identical results, through in-kernel resets"""
+    L, n, T = qd._lib, 300, 40
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, random_params=1, auto_reset=1, max_steps=9, seed=11))
+    a, b = mk(), mk()
+    a.reset()
+    g = torch.Generator(device="cuda").manual_seed(1)
+    for _ in range(13):                                    # advance a: some envs mid-episode, some freshly re-sampled
+        a.step(torch.rand((n, 4), generator=g, device="cuda"))
+    b.arena.copy_(a.arena)                                 # "load the checkpoint" (b was never reset or stepped)
+    for t in range(T):
+        act = torch.rand((n, 4), generator=g, device="cuda")
+        oa, ra, ta = a.step(act)
+        ob, rb, tb = b.step(act)
+        assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb), t
+    for x, y in zip(a.get_state(), b.get_state()):
+        assert torch.equal(x, y)
