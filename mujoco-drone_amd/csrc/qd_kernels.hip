@@ -644,6 +644,11 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
   float* otile = small + S4 * 4;           // [16][D] observation rows: obs0, then what the env step of the last iteration wrote
   float* atile = otile + POL_TILE * D;     // [16][4] actions of the last iteration (previous action of the next)
   uint8_t* trt = reinterpret_cast<uint8_t*>(atile + POL_TILE * AD);  // [16] truncated flags of the last iteration
+  // [16][aux_dim] the parameter embedding z of the first step (networks with fused_const_ops), behind the 64 bytes reserved for trt
+  constexpr unsigned CONST_OPS = fused_const_ops<A>;
+  constexpr int ZD = CONST_OPS ? A::prog.aux_dim : 0;
+  float* ztile = atile + POL_TILE * AD + 16;
+  constexpr int z_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, z_ld = sp_ld(A::prog, A::prog.aux_buf);
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int env0 = blockIdx.x * POL_TILE, rows = min(POL_TILE, a.n - env0), n = a.n;
   SCtx c;
@@ -652,6 +657,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
   c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
   c.n_envs = rows; c.env0 = 0; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
+  c.skip_ops = 0u;
   SPre<A, J0> pre;
   s_prefetch<A, J0>(c, pre);
   {  // prologue: parameters mirror, first observation / previous action, cleared activations
@@ -688,8 +694,14 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
     for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;  // the input buffers also held last step's outputs
     __syncthreads();
     lead.store(c);
+    if (CONST_OPS && t > 0)  // z of step 0 back into its slice of the input buffer (cleared above); the encoder ops are skipped
+      for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
     __syncthreads();
     s_run<A, LC, J0>(c, pre);
+    if (CONST_OPS && t == 0) {  // the embedding is final once the program has run: keep it for the rest of the fragment
+      for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) ztile[k] = lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)];
+      c.skip_ops = CONST_OPS;
+    }
     s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs and the env step
     if (has_value && c.want_value && tid < rows) value[(size_t)t * n + env0 + tid] = lds[v_base + tid * v_ld];
     PolSample st = smp;

@@ -264,6 +264,14 @@ struct ArchDsnLstm {  // DSN_LSTM_model (mujoco_drone_amd/policy.py; table print
   X(7, ArchCustomMlp) X(8, ArchLstmEst) X(9, ArchRmaSmaller) X(10, ArchRmaSmaller2) X(11, ArchCustomLstm)              \
   X(12, ArchLstmBigger) X(13, ArchLstmCommonF) X(14, ArchDsnLstm)
 
+// Ops whose result depends on the drone parameters only (the parameter encoder of the RMA networks, writing the auxiliary slice z):
+// within one fused rollout the parameters of an env do not change (in-kernel resets keep them; regeneration is a host call
+// between fragments), so k_rollout_fused runs them on the first step only and keeps z in LDS.
+template <class A> constexpr unsigned fused_const_ops = 0u;
+template <> constexpr unsigned fused_const_ops<ArchRmaFull> = (1u << 3) | (1u << 4);
+template <> constexpr unsigned fused_const_ops<ArchRmaModel> = (1u << 3) | (1u << 4);
+template <> constexpr unsigned fused_const_ops<ArchRmaSmaller> = (1u << 3) | (1u << 4);
+
 // ---- the specialised kernel ----
 struct SCtx {
   float* lds;
@@ -277,6 +285,7 @@ struct SCtx {
   const float* small_global;  // the small region in the blob (the prologue reads ring fill values before the LDS mirror exists)
   float* state;            // per-env history rings (windowed networks)
   unsigned counter;        // the caller's step counter: selects ring slots and banks
+  unsigned skip_ops;       // bit I set: op I is skipped (fused rollouts: the parameter encoder after the first step); 0 elsewhere
 };
 
 constexpr int SPF = 8;  // k-blocks of the next dense layer requested before the current layer's barrier
@@ -514,7 +523,7 @@ template <class A, int I, int J>
 __device__ __forceinline__ void s_run(const SCtx& c, const SPre<A, J>& pre) {
   if constexpr (I < A::prog.n_ops) {
     constexpr SOp op = A::prog.op[I];
-    const bool runs = c.want_value || !(op.flags & POL_FLAG_VALUE_ONLY);  // uniform over the workgroup
+    const bool runs = (c.want_value || !(op.flags & POL_FLAG_VALUE_ONLY)) && !((c.skip_ops >> I) & 1u);  // uniform over the workgroup
     if constexpr (op.kind == POL_DENSE) {
       static_assert(I == J, "prefetch bookkeeping");
       constexpr int JN = sp_next_dense(A::prog, I + 1);
@@ -558,7 +567,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
-  c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter;
+  c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter; c.skip_ops = 0u;
   // the first dense layer's weights are requested before anything else
   constexpr int J0 = sp_next_dense(A::prog, 0);
   POL_STAMP(0);
