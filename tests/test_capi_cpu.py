@@ -138,3 +138,12 @@ def test_header_is_plain_c_and_the_c_example_links(tmp_path):
     subprocess.check_call(["gcc", "-std=c99", "-O2", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(rocm, "include"),
                            os.path.join(ROOT, "examples", "capi_hover.c"), "-o", str(tmp_path / "capi_hover"), "-L", libdir, "-lqd",
                            "-L", os.path.join(rocm, "lib"), "-lamdhip64", "-lm", "-Wl,-rpath," + libdir, "-Wl,-rpath," + os.path.join(rocm, "lib")])
+
+
+def test_integration_doc_names_every_entry_point():
+    """INTEGRATION.md maps each function of include/qd.h to the reference interface it replaces: none may be missing"""
+    header = open(os.path.join(ROOT, "include", "qd.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    names = sorted(set(re.findall(r"\b(qd_[a-z_]+)\s*\(", header)))
+    assert len(names) >= 40
+    assert [n for n in names if n not in doc] == []
