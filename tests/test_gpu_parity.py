@@ -978,3 +978,41 @@ def test_arena_is_the_whole_device_state(qd):
         assert torch.equal(oa, ob) and torch.equal(ra, rb) and torch.equal(ta, tb), t
     for x, y in zip(a.get_state(), b.get_state()):
         assert torch.equal(x, y)
+
+
+def test_config5_full_size_8192_envs(qd, orc):
+    """BASELINE config 5 at its quoted size through the Python mirror: 8192 envs, LocalFrameFullStateEnv, distance_energy_reward_pendulum_en4,
+    state_difficulty 0.8, per-env circle waypoint generated in the kernel.  A sample of envs against the oracle from the device's
+    own initial states (the waypoint phase depends on the env index AND the batch size), then invariants over the whole batch"""
+    import bench
+    n, steps = 8192, 30
+    env, _ = bench.make_env("config5", n, 42, "cuda:0", auto_reset=False)
+    env.vector_reset_tensor()
+    L = qd._lib
+    q0, v0, a0, _, _ = [x.cpu().numpy().astype(np.float64) for x in env._dev.get_state()]
+    raw = env._dev.get_params().cpu().numpy()
+    sample = np.r_[0:8, 4093:4099, n - 8:n]
+    models = {i: orc.build_model(raw[i]) for i in sample}
+    oq = {i: q0[i].copy() for i in sample}; ov = {i: v0[i].copy() for i in sample}; oa = {i: a0[i].copy() for i in sample}
+    ok, rk = L.OBS_KINDS.index("LocalFrameFullStateEnv"), L.REWARD_KINDS.index("distance_energy_reward_pendulum_en4")
+    centre = np.array([float(x) for x in env.reference])
+    g = torch.Generator(device="cuda").manual_seed(3)
+    for k in range(steps):
+        a = torch.rand((n, 4), generator=g, device="cuda")
+        o, r, tr = env.vector_step_tensor(a)
+        o, r, an = o.cpu().numpy(), r.cpu().numpy(), a.cpu().numpy()
+        assert np.all(np.isfinite(o)) and np.all(np.isfinite(r))
+        for i in sample:
+            ph = 2 * np.pi * 0.5 * k * 0.01 + 2 * np.pi * i / n
+            ref = centre + np.array([np.cos(ph), np.sin(ph), 0.0, 0.0])
+            q, v, aa, sens = orc.step(models[i], 0.01, 1, oq[i], ov[i], oa[i], 0.1 + 0.9 * an[i].astype(np.float64))
+            oq[i], ov[i], oa[i] = q, v, aa
+            s = orc.drone_state(1, q, v, sens, aa, ref, raw[i])
+            np.testing.assert_allclose(o[i], orc.obs(ok, s, ref), rtol=2e-4, atol=3e-3, err_msg="env %d step %d" % (i, k))
+            assert abs(r[i] - orc.reward(rk, s, an[i], k + 1, ref, 4.0)) < 2e-3 * max(1.0, abs(r[i])), (i, k)
+    st = env._dev.drone_states().cpu().numpy()
+    ph = 2 * np.pi * 0.5 * steps * 0.01 + 2 * np.pi * np.arange(n) / n
+    np.testing.assert_allclose(st[:, 23], centre[0] + np.cos(ph), atol=2e-5)
+    np.testing.assert_allclose(st[:, 24], centre[1] + np.sin(ph), atol=2e-5)
+    q = env._dev.get_state()[0]
+    assert torch.allclose(q[:, 3:7].norm(dim=1), torch.ones(n, device=q.device), atol=1e-5)
