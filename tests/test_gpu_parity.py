@@ -640,6 +640,33 @@ def test_config3_full_size_4096_envs_200_steps(qd, orc):
     np.testing.assert_allclose(r.cpu().numpy(), orr, rtol=2e-4, atol=2e-3)
 
 
+def test_config2_full_size_4096_simple_drones_200_steps(qd, orc):
+    """BASELINE config 2 at its full size: 4096 SimpleDrone envs (no load, 1 kHz, 2 substeps per step, direct ctrl), fixed initial
+    state, 200 steps of U[0.5, 1) rotor actions; every env against the float64 oracle, target <= 1e-4 relative"""
+    rng = np.random.default_rng(321)
+    n, L, steps = 4096, qd._lib, 200
+    c = make_cfg(L, n, load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, h=0.001, ctrl_map=0, term=1,
+                 ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0), max_steps=10 ** 6, max_distance=1e9)
+    env = qd.dev.DeviceEnv(c)
+    raw = np.tile([1.35, 0.15, 7.5, 0.015, 0, 0], (n, 1))
+    env.set_params(raw)
+    q0 = np.tile([0, 0, 1, 1, 0, 0, 0.0], (n, 1))
+    env.set_state(q0, np.zeros((n, 6)), np.zeros((n, 4)))
+    ob = orc.Batch(raw, False, L.OBS_KINDS.index("SimpleDrone"), L.REWARD_KINDS.index("simple_drone_reward"), 0.001, 2, 0, (0, 0, 1, 0), 1e9, 10 ** 6)
+    ob.qpos[:], ob.qvel[:], ob.act[:] = q0, 0.0, 0.0
+    acts = rng.uniform(0.5, 1.0, (steps, n, 4)).astype(np.float32)
+    for t in range(steps):
+        o, r, tr = env.step(acts[t])
+        oo, orr, otr = ob.step(acts[t].astype(np.float64), threads=8)
+    gq, gv, ga, _, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(gk == steps)
+    err = max(float(np.max(np.abs(g - w) / np.maximum(1.0, np.abs(w)))) for g, w in ((gq, ob.qpos), (gv, ob.qvel), (ga, ob.act)))
+    print("config 2, 4096 envs, 200 steps: max relative state divergence %.3e" % err)
+    assert err < 1e-4
+    np.testing.assert_allclose(o.cpu().numpy(), oo, rtol=2e-4, atol=2e-4)
+    np.testing.assert_allclose(r.cpu().numpy(), orr, rtol=2e-4, atol=2e-4)
+
+
 def test_determinism_and_long_run_stability(qd):
     """same seed -> bit-identical runs; 3000 auto-resetting steps at 4096 envs stay finite and consistent"""
     L, n = qd._lib, 4096
