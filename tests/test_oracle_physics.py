@@ -228,3 +228,24 @@ def test_floor_contact_of_the_hanging_load(orc):
         assert np.all(np.isfinite(qpos)) and fz >= 0
     cons = orc.floor_contacts(m, qpos)
     assert seen > 0 and all(b == 2 for _, _, b in cons)
+
+
+def test_torque_free_precession_of_the_airframe(orc):
+    """Textbook anchor for the gyroscopic term: a free symmetric top (Ix = Iy) spinning about z with a small transverse rate
+    precesses in the body frame, wx + i wy = eps exp(i Omega t) with Omega = (Iz - Ix) / Ix * wz.  No gravity, air or thrust."""
+    m = _model(orc, 0)
+    m.density = m.viscosity = 0.0
+    m.gravity = 0.0
+    Ix, Iy, Iz = m.I0full[0], m.I0full[1], m.I0full[2]
+    assert abs(Ix - Iy) < 1e-3 * Ix                      # the four arms at +-45 degrees make it a symmetric top (to the XML's rounding)
+    wz, eps, h, n = 25.0, 0.05, 2e-5, 20000                # explicit Euler grows the amplitude by (Omega h)^2 / 2 per step: 0.2 % here
+    qpos = np.array([0, 0, 5, 1, 0, 0, 0.0]); qvel = np.array([0, 0, 0, eps, 0, wz]); act = np.zeros(4)
+    Omega = (Iz - 0.5 * (Ix + Iy)) / (0.5 * (Ix + Iy)) * wz
+    for k in range(n):
+        qpos, qvel, act, _ = orc.step(m, h, 1, qpos, qvel, act, np.zeros(4))
+    t = n * h
+    want = eps * np.exp(1j * Omega * t)
+    got = qvel[3] + 1j * qvel[4]
+    assert abs(got - want) < 5e-3 * eps, (got, want, Omega)
+    assert abs(np.angle(got / want)) < 1e-3                # the precession phase itself: Omega t to a milliradian
+    assert abs(qvel[5] - wz) < 1e-9 * wz
