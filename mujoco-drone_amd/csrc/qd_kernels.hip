@@ -1567,10 +1567,19 @@ static void epi_layout(int num_envs, int S, size_t* ret_off, size_t* len_off, si
   *total = *part_off + (size_t)(S + 1) * G * qd::EPI_FIELDS * sizeof(double);
 }
 
+// time segments per fragment: enough (segment, env-group) workgroups to fill the chip a few times over -- 64 segments for the
+// BASELINE batch sizes, fewer when the env axis alone supplies the parallelism (the summaries cost 24 bytes per segment and env)
+static int epi_max_segments(int num_envs) {
+  const int G = (num_envs + qd::STAT_THREADS - 1) / qd::STAT_THREADS;
+  int s = 4096 / G;
+  if (s > qd::EPI_MAX_SEGMENTS) s = qd::EPI_MAX_SEGMENTS;
+  return s < 1 ? 1 : s;
+}
+
 size_t qd_episode_stats_workspace_bytes(int num_envs) {
   if (num_envs < 1) return 0;
   size_t a, b, c, total;
-  epi_layout(num_envs, qd::EPI_MAX_SEGMENTS, &a, &b, &c, &total);
+  epi_layout(num_envs, epi_max_segments(num_envs), &a, &b, &c, &total);
   return total;
 }
 
@@ -1581,8 +1590,8 @@ int qd_episode_stats(const float* reward, const uint8_t* truncated, int T, int n
   if (workspace_bytes < qd_episode_stats_workspace_bytes(num_envs) || (reinterpret_cast<uintptr_t>(workspace) & 15))
     return fail(QD_ERR_ARENA, "workspace too small (qd_episode_stats_workspace_bytes) or not 16-byte aligned");
   const int G = (num_envs + qd::STAT_THREADS - 1) / qd::STAT_THREADS;
-  // short walks: as many segments as the workspace is sized for, none shorter than 8 steps
-  int nseg = qd::EPI_MAX_SEGMENTS;
+  // short walks: as many segments as the workspace is sized for (epi_max_segments), none shorter than 8 steps
+  int nseg = epi_max_segments(num_envs);
   if (nseg > T / qd::EPI_MIN_SEGMENT) nseg = T / qd::EPI_MIN_SEGMENT;
   if (nseg < 1) nseg = 1;
   const int L = T > 0 ? (T + nseg - 1) / nseg : 1;
