@@ -652,3 +652,15 @@ def test_evaluate_trajectory_lstmest_history_window_like_reference(PG):
         logits, _, _ = P.cnn_estimator_hist(w, hist_o, hist_a)
         np.testing.assert_allclose(dev_act[t, 0], P.beta_mean_action(logits)[0], atol=3e-5, err_msg="t=%d" % t)
     np.testing.assert_allclose(np.asarray(actions), dev_act[:, 0], atol=0)
+
+
+def test_collection_loop_example_runs():
+    """examples/collect_fragments.py: env + exploring actor + batch / episode statistics, fragment after fragment, on one GPU"""
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("collect_fragments", os.path.join(os.path.dirname(HERE), "examples", "collect_fragments.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    log = mod.main(num_envs=512, fragment=64, fragments=3, quiet=True)
+    assert len(log) == 3 and all(np.isfinite(x[2]) and x[3] > 0 for x in log)
