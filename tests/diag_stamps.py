@@ -1,5 +1,6 @@
 """Diagnostic (not a test): per-phase cycle shares of the step kernel from a -DQD_STAMPS build.
-usage: QD_LIB=tests/_build/libqd_diag.so python tests/diag_stamps.py"""
+usage: QD_LIB=tests/_build/libqd_diag.so [QD_DIAG_CONFIG=config5 QD_DIAG_ENVS=8192] python tests/diag_stamps.py
+(build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc -DQD_STAMPS -o tests/_build/libqd_diag.so mujoco-drone_amd/csrc/qd_kernels.hip)"""
 import ctypes as C
 import os
 import sys
@@ -11,9 +12,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import bench  # noqa: E402
 
-env, _ = bench.make_env("config3", 4096, 42, "cuda:0")
+CFG, N = os.environ.get("QD_DIAG_CONFIG", "config3"), int(os.environ.get("QD_DIAG_ENVS", 4096))
+env, _ = bench.make_env(CFG, N, 42, "cuda:0")
 env.vector_reset_tensor()
-a = torch.rand((8, 4096, 4), device="cuda")
+a = torch.rand((8, N, 4), device="cuda")
 for i in range(300):
     env._dev.step(a[i % 8])
 torch.cuda.synchronize()
