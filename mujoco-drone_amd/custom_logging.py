@@ -65,6 +65,20 @@ class BatchStatistics:
         return result
 
 
+def merge_column_stats(parts, rows):
+    """Combine the column statistics of several shards of one train batch (e.g. one per rank after the fragment all-gather) into
+    those of the whole batch: `parts` = dicts / [4, cols] arrays (min, max, mean, var) as `BatchStatistics.column_stats` returns,
+    `rows` = the shards' row counts.  Host arithmetic on a few dozen numbers (parallel-variance formula), float64."""
+    arr = [np.stack([p["min"], p["max"], p["mean"], p["var"]]) if isinstance(p, dict) else np.asarray(p, dtype=np.float64) for p in parts]
+    n = np.asarray(rows, dtype=np.float64)
+    if len(arr) != len(n) or len(arr) == 0 or np.any(n <= 0):
+        raise ValueError("merge_column_stats needs one positive row count per shard")
+    total = n.sum()
+    mean = sum(a[2] * k for a, k in zip(arr, n)) / total
+    var = sum((a[3] + (a[2] - mean) ** 2) * k for a, k in zip(arr, n)) / total
+    return {"min": np.minimum.reduce([a[0] for a in arr]), "max": np.maximum.reduce([a[1] for a in arr]), "mean": mean, "var": var}
+
+
 class EpisodeStatistics:
     """episode returns and lengths from rollout fragments (qd_episode_stats); the running episode of every env is carried
     from one fragment to the next"""

@@ -49,3 +49,25 @@ def test_stats_entry_points_validate_on_the_host():
     assert lib.qd_column_stats(dummy, 0, 22, dummy, dummy, 1 << 30, None) == L.QD_ERR_INVALID and "empty batch" in L.last_error()
     assert lib.qd_column_stats(dummy, 10, 22, dummy, dummy, 8, None) == L.QD_ERR_ARENA
     assert lib.qd_episode_stats(dummy, dummy, 4, 8, None, dummy, dummy, 1 << 20, None) == L.QD_ERR_INVALID
+
+
+def test_merge_of_shard_statistics_equals_statistics_of_the_whole(SG):
+    """config 4: every rank computes the statistics of its own fragment; the learner merges them (host arithmetic only, so this
+    runs without a GPU: the shard statistics here come from the oracle)"""
+    from oracle import stats_ref as S
+    import importlib
+    x = SG["batch_obs"].astype(np.float64)
+    cuts = [0, 700, 701, 2100, len(x)]
+    parts = [S.column_stats(x[a:b]) for a, b in zip(cuts, cuts[1:])]
+    rows = [b - a for a, b in zip(cuts, cuts[1:])]
+    try:
+        merge = importlib.import_module("mujoco_drone_amd.custom_logging").merge_column_stats
+    except ImportError as ex:                                  # the module needs the built library; the merge itself does not
+        pytest.skip(str(ex))
+    got, want = merge(parts, rows), S.column_stats(x)
+    for k in ("min", "max"):
+        np.testing.assert_array_equal(got[k], want[k])
+    np.testing.assert_allclose(got["mean"], want["mean"], rtol=1e-13)
+    np.testing.assert_allclose(got["var"], want["var"], rtol=1e-11)
+    with pytest.raises(ValueError):
+        merge(parts, rows[:-1])
