@@ -13,10 +13,24 @@ place into [T=1024,N,...] trajectory fragments.  The envs are independent, so th
 collective; the per-fragment RCCL all-gather that concatenates trajectories for a central learner is
 measured separately (alone and overlapped with stepping) and reported under config.trajectory_all_gather
 (SURVEY.md 8e).  Actions are synthetic U[0,1) tensors already resident in HBM.  Prints ONE JSON line.
+
+Launching: under torchrun (WORLD_SIZE set) every process is one rank.  Started plainly with --gpus N > 1 the
+process becomes a launcher: it starts N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
+their environment) BEFORE touching torch or the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
+
+Every step is one k_step kernel launch.  Steps are issued through qd_step_fragment (one C call per run of steps
+inside a [T,N,...] fragment): launch by launch for runs shorter than 128 steps, as a replayed HIP graph above
+(captured during the untimed ramp, never inside the timed region).  `roofline.kernel_us` does not depend on --steps:
+it is the per-launch period of 4096 back-to-back k_step launches between two HIP events on the launch stream.
+
+--dry: rehearsal of the launcher / distributed / fragment all-gather plumbing on CPU tensors (gloo), no GPU, no env
+stepping (the fragments are filled with a rank pattern); the line says "dry_run": true and is not a measurement.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -26,6 +40,7 @@ if ROOT not in sys.path:
 
 ALG_BYTES = {"load22": 309, "noload6": 181, "load23": 329}  # algorithmic bytes per env-step
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
+KERNEL_PERIOD_LAUNCHES = 4096  # fixed length of the per-launch period measurement behind roofline.kernel_us
 WORKLOADS = {
     "config3": "BASELINE config 3: drone + hanging load, domain-randomised params, LocalFrameRPYParamsEnv obs (D=22), "
                "distance_energy_reward, max_steps=1024, regen every 1024 steps, in-kernel auto-reset",
@@ -33,6 +48,7 @@ WORKLOADS = {
     "config5": "BASELINE config 5: drone + load, LocalFrameFullStateEnv obs (D=23), distance_energy_reward_pendulum_en4, "
                "state_difficulty 0.8, per-env moving circle waypoint (r=1, f=0.5 Hz) generated in the step kernel",
 }
+OBS_DIM = {"config3": 22, "config2": 6, "config5": 23}
 
 
 def make_env(kind, n, seed, device, auto_reset=True):
@@ -119,8 +135,9 @@ def cpu_baseline(seconds_target=12.0, threads=None):
 
 
 def kernel_time_us(env, actions, samples=200):
-    """average duration of ONE step-kernel launch, HIP events on the launch stream around single launches
-    issued on an idle stream (minus the cost of an empty event pair)"""
+    """duration of ONE step-kernel launch issued on an idle stream: HIP events around single launches
+    (minus the cost of an empty event pair).  Includes the launch latency from idle; reported as a side figure."""
+    import statistics
     import torch
     s = torch.cuda.current_stream()
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(samples)]
@@ -137,14 +154,32 @@ def kernel_time_us(env, actions, samples=200):
         em[i][0].record(s)
         em[i][1].record(s)
     torch.cuda.synchronize()
-    import statistics
     t = statistics.median(a.elapsed_time(b) for a, b in ev) * 1e3
     e = statistics.median(a.elapsed_time(b) for a, b in em) * 1e3
     return max(t - e, 1e-3), t, e
 
 
+def kernel_period_us(env, frag, launches=KERNEL_PERIOD_LAUNCHES):
+    """per-launch period of `launches` back-to-back k_step launches (graph-replayed fragments, no host in the loop),
+    between two HIP events recorded on the launch stream: the kernel's average duration plus the kernel boundary -- what
+    rocprofv3's kernel trace reports for back-to-back dispatches.  Fixed length: independent of --steps."""
+    import torch
+    T = frag.T
+    reps = max(1, launches // T)
+    dev = env._dev
+    dev.step_fragment(frag.actions, frag.obs, frag.rewards, frag.truncated)   # capture (if new) + clock
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dev.step_fragment(frag.actions, frag.obs, frag.rewards, frag.truncated)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) * 1e3 / (reps * T), reps * T
+
+
 def stream_rate_us(env, actions, launches=4000):
-    """back-to-back launches, whole region between two events: per-launch period when the GPU queue is full"""
+    """back-to-back per-step API launches, whole region between two events (host launch path included)"""
     import torch
     step = env._dev.step
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -158,92 +193,150 @@ def stream_rate_us(env, actions, launches=4000):
     return a.elapsed_time(b) * 1e3 / launches
 
 
-def main():
+# ------------------------------------------------------------------------------------------- launcher
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n_ranks, argv):
+    """start one process per rank (the torchrun contract, without torchrun) and relay rank 0's stdout.  Nothing in this
+    process has imported torch or touched the GPU; the ranks are children, never an exec of this process."""
+    env = dict(os.environ)
+    env.update(WORLD_SIZE=str(n_ranks), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()), LOCAL_WORLD_SIZE=str(n_ranks))
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    procs = []
+    import tempfile
+    with tempfile.TemporaryFile() as out0_file:
+        try:
+            for r in range(n_ranks):
+                e = dict(env, RANK=str(r), LOCAL_RANK=str(r))
+                procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=e,
+                                              stdout=out0_file if r == 0 else subprocess.DEVNULL))
+            # a rank that dies leaves the others waiting in a rendezvous or a collective: end them (exact PIDs) right away
+            while any(p.poll() is None for p in procs):
+                if any(p.poll() not in (None, 0) for p in procs):
+                    for p in procs:
+                        if p.poll() is None:
+                            p.kill()
+                time.sleep(0.05)
+            codes = [p.wait() for p in procs]
+        except BaseException:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            raise
+        out0_file.seek(0)
+        out0 = out0_file.read().decode()
+    sys.stdout.write(out0)
+    sys.stdout.flush()
+    bad = [(r, c) for r, c in enumerate(codes) if c != 0]
+    if bad:
+        sys.stderr.write("bench: rank(s) failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
+        return 1
+    return 0
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8192)
     ap.add_argument("--warmup", type=int, default=512)
     ap.add_argument("--envs", type=int, default=4096, help="envs per GPU")
     ap.add_argument("--config", default="config3", choices=["config3", "config2", "config5"])
-    ap.add_argument("--fragment", type=int, default=1024, help="steps per all-gathered trajectory fragment (N>1)")
+    ap.add_argument("--fragment", type=int, default=1024, help="steps per trajectory fragment")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true")
-    args = ap.parse_args()
+    ap.add_argument("--dry", action="store_true", help="CPU rehearsal of launcher + distributed plumbing; not a measurement")
+    return ap.parse_args(argv)
+
+
+def main():
+    args = parse_args()
+    if args.gpus < 1 or args.steps < 1 or args.warmup < 0 or args.fragment < 1:
+        raise SystemExit("bench: --gpus/--steps/--fragment must be >= 1, --warmup >= 0")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
 
     import torch
     import torch.distributed as dist
     from mujoco_drone_amd import parallel as par
+    if args.dry:
+        os.environ.setdefault("QD_DIST_BACKEND", "gloo")
     rank, world, local = par.init_distributed()
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    assert torch.cuda.is_available(), "bench.py needs a GPU"
-    if os.environ.get("QD_SINGLE_DEVICE"):   # rehearsal of the N>1 path on a one-GPU box (with QD_DIST_BACKEND=gloo)
-        local = 0
-    torch.cuda.set_device(local)
-    device = "cuda:%d" % local
-    n, K, W = args.envs, args.steps, args.warmup
-
-    env, alg = make_env(args.config, n, par.shard_seed(42, rank), device)
-    step = env.vector_step_tensor if args.config != "config2" else env.step_tensor
-    if args.config != "config2":
-        env.vector_reset_tensor()
-        D = env._dev.D
+    n, K, W, T = args.envs, args.steps, args.warmup, args.fragment
+    host_wait = "runtime default"
+    if args.dry:
+        device, env, alg, D = "cpu", None, {"config3": "load22", "config2": "noload6", "config5": "load23"}[args.config], OBS_DIM[args.config]
     else:
-        env.reset()
-        D = 6
+        assert torch.cuda.is_available(), "bench.py needs a GPU"
+        if os.environ.get("QD_SINGLE_DEVICE"):   # rehearsal of the N>1 path on a one-GPU box (with QD_DIST_BACKEND=gloo)
+            local = 0
+        torch.cuda.set_device(local)
+        device = "cuda:%d" % local
+        torch.zeros(1, device=device)            # the device's runtime state exists before its wait mode is set
+        if not os.environ.get("QD_BENCH_NO_SPIN"):
+            # host threads busy-wait in synchronize (hipDeviceScheduleSpin): a timed region of 20 five-microsecond steps
+            # should not end with an interrupt round trip; reported in config.host_wait
+            from mujoco_drone_amd import _lib as L_
+            L_.check(L_.lib().qd_host_wait_spin(1))
+            host_wait = "spin (hipDeviceScheduleSpin)"
+        env, alg = make_env(args.config, n, par.shard_seed(42, rank), device)
+        if args.config != "config2":
+            env.vector_reset_tensor()
+            D = env._dev.D
+        else:
+            env.reset()
+            D = 6
     lo, hi = (0.0, 1.0) if args.config != "config2" else (0.5, 1.0)
-    P = 64
     g = torch.Generator(device=device); g.manual_seed(1000 + rank)
-    actions = lo + (hi - lo) * torch.rand((P, n, 4), generator=g, device=device, dtype=torch.float32)
 
-    T = min(args.fragment, K)
-    # Rollout fragments [T,N,...] the step kernel writes in place; the synthetic actions live in the fragment's action
-    # tensor itself -- where a policy would write them.  Every step is one k_step launch (qd_step); the T launches of a
-    # fragment are enqueued as ONE HIP graph (qd_step_fragment: captured on first use, replayed afterwards), because at
-    # 4096 envs the per-launch host path (4-5.5 us depending on the host CPU) is what bounds a step-by-step loop, not the
-    # 4.1 us kernel.  Steps that do not fill a fragment go through the per-step call.  The envs never exchange data, so
-    # the timed region has no collective; with N > 1 the per-fragment RCCL all-gather that hands trajectories
-    # to a central learner is measured right after it, alone and overlapped with stepping, and reported separately.
-    pending = [None, None]
-    use_graph = not os.environ.get("QD_BENCH_NO_GRAPH")
+    # Rollout fragments [T,N,...] the step kernel writes in place; the synthetic actions live in the fragment's action tensor
+    # itself -- where a policy would write them.  Two fragments alternate (one can be all-gathered while the other fills).
     frags = [par.FragmentBuffers(T, n, D, device) for _ in range(2)]
     gathers = [par.FragmentGather(f, world) for f in frags] if world > 1 else None
     for f in frags:
         f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
-    state = {"cur": 0, "gathers": 0, "graph_steps": 0, "call_steps": 0, "use_graph": use_graph}
-    # per-step slices of the fragments, made once (tensor indexing costs more than the launch it feeds)
-    views = [[(f.actions[t], (f.obs[t], f.rewards[t], f.truncated[t])) for t in range(T)] for f in frags]
+    pending = [None, None]
+    state = {"cur": 0, "pos": 0, "gathers": 0, "graph_steps": 0, "direct_steps": 0, "total": 0}
+    graph_min = int(os.environ.get("QD_GRAPH_MIN_STEPS", "128"))
+    if args.dry:
+        def step_run(f, p, c):   # no env: stamp the slice so that the gather test can tell ranks and steps apart
+            f.obs[p:p + c].fill_(float(rank + 1))
+            f.rewards[p:p + c].fill_(float(rank + 1))
+            f.truncated[p:p + c].fill_(rank + 1)
+    elif args.config == "config2":
+        def step_run(f, p, c):
+            env._dev.step_fragment(f.actions[p:p + c], f.obs[p:p + c], f.rewards[p:p + c], f.truncated[p:p + c])
+    else:
+        def step_run(f, p, c):
+            env.step_fragment_tensor(f.actions[p:p + c], f.obs[p:p + c], f.rewards[p:p + c], f.truncated[p:p + c])
 
-    def run(k_steps, base=0, gather=False):
-        t = 0
-        while t < k_steps:
-            tt = (base + t) % T
-            cur = state["cur"]
-            if gather and tt == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
+    def run(k_steps, gather=False):
+        """k_steps vector_steps, written at the running position of the current fragment"""
+        while k_steps > 0:
+            cur, pos = state["cur"], state["pos"]
+            if gather and pos == 0 and pending[cur] is not None:      # this buffer's previous gather must have drained
                 for w in pending[cur]:
                     w.wait()
                 pending[cur] = None
-            f = frags[cur]
-            if state["use_graph"] and tt == 0 and k_steps - t >= T:
-                try:
-                    env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
-                except Exception as ex:      # a runtime that cannot capture: fall back to per-step calls for the rest of the run
-                    state["use_graph"] = False
-                    print("bench: HIP graph path disabled (%r)" % (ex,), file=sys.stderr)
-                    continue
-                state["graph_steps"] += T
-                t += T
-                tt = T - 1
-            else:
-                a_t, out_t = views[cur][tt]
-                step(a_t, out=out_t)
-                state["call_steps"] += 1
-                t += 1
-            if tt == T - 1:
+            c = min(k_steps, T - pos)
+            step_run(frags[cur], pos, c)
+            state["graph_steps" if c >= graph_min else "direct_steps"] += c
+            state["total"] += c
+            k_steps -= c
+            pos += c
+            if pos == T:
                 if gather:
-                    pending[cur] = gathers[cur](f, async_op=True)[1]
+                    pending[cur] = gathers[cur](frags[cur], async_op=True)[1]
                     state["gathers"] += 1
-                state["cur"] = cur ^ 1
+                state["cur"], pos = cur ^ 1, 0
+            state["pos"] = pos
 
     def drain():
         for b in range(2):
@@ -252,38 +345,60 @@ def main():
                     w.wait()
                 pending[b] = None
 
+    def sync():
+        if not args.dry:
+            torch.cuda.synchronize()
+
     def fence():
-        torch.cuda.synchronize()
+        sync()
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+            sync()
 
-    # clock ramp: a fresh process finds the GPU in a low power state and a 4 us kernel every 5 us takes tens of ms to pull the
-    # shader clock up (measured: the same K steps are 2-12 % slower after 512 untimed steps than after 8192).  These extra
-    # untimed steps come before the W warmup steps of the contract and are reported in config.clock_ramp_steps.
-    ramp = (8192 + T - 1) // T * T - W        # >= 8192 - W steps, and the timed region starts on a fragment boundary
-    while ramp < 0:
-        ramp += T
-    ramp_s = float(os.environ.get("QD_BENCH_RAMP_S", "0"))
-    if ramp_s > 0:
+    def to_boundary():
+        if state["pos"]:
+            run(T - state["pos"])
+
+    def prepare():
+        """the W warmup steps of the contract, placed so that they END on a fragment boundary: the timed steps then start
+        at row 0 of a fragment (whole fragments = the [0, T) graphs the ramp has already captured)"""
+        run((T - W % T) % T)
+        run(W)
+
+    # Untimed preparation.  (1) clock ramp: a fresh process finds the GPU in a low power state and a 4 us kernel every 5 us
+    # takes tens of ms to pull the shader clock up (measured: the same K steps are 2-12 % slower after 512 untimed steps than
+    # after 8192).  (2) rehearsal: the exact call sequence of the warmup + timed steps runs once on the same fragment buffers,
+    # so every HIP graph the timed region replays already exists (a capture + instantiate costs ~20 us per node).  Both come
+    # before the W warmup steps of the contract and are reported in config.clock_ramp_steps.
+    if not args.dry:
+        ramp_s = float(os.environ.get("QD_BENCH_RAMP_S", "0"))
         t_r = time.perf_counter()
-        while time.perf_counter() - t_r < ramp_s:
-            run(8192, base=ramp)
-            ramp += 8192
-            torch.cuda.synchronize()
-    else:
-        run(ramp)
-    run(W, base=ramp)
+        while state["total"] < 8192 or time.perf_counter() - t_r < ramp_s:
+            run(T)
+            if state["total"] % (8 * T) == 0:
+                sync()
+        cur0 = state["cur"]
+        if W + K <= 65536:
+            prepare()
+            run(K)
+            to_boundary()
+            state["cur"] = cur0      # at a boundary either buffer can be the current one: replay on the rehearsed ones
+        sync()
+    prepare()
+    ramp = state["total"] - W     # every untimed step before the W warmup steps
     fence()
-    state["graph_steps"] = state["call_steps"] = 0
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    state["graph_steps"] = state["direct_steps"] = 0
+    if not args.dry:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
-    ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
-    run(K, base=ramp + W)
-    ev1.record()
+    if not args.dry:
+        ev0.record()           # HIP events on the stream the step kernels are launched on (torch's current stream)
+    run(K)
+    if not args.dry:
+        ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    timed_graph_steps, timed_call_steps = state["graph_steps"], state["call_steps"]
+    timed_graph_steps, timed_direct_steps = state["graph_steps"], state["direct_steps"]
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -295,8 +410,9 @@ def main():
             t_ = torch.tensor([x], dtype=torch.float64, device=device)
             dist.all_reduce(t_, op=dist.ReduceOp.MAX)
             return float(t_.item())
+        to_boundary()
         # (i) one fragment all-gather alone
-        gathers[0](frags[0])
+        gathered, _ = gathers[0](frags[0])
         fence()
         t1 = time.perf_counter()
         reps = 3
@@ -304,19 +420,25 @@ def main():
             gathers[0](frags[0])
         fence()
         gather_ms = maxed((time.perf_counter() - t1) / reps * 1e3)
+        # every rank must now hold every rank's fragment: row r of the gathered rewards is rank r's
+        ok = True
+        if args.dry:
+            ok = all(bool((gathered["rewards"][r] == float(r + 1)).all()) and bool((gathered["truncated"][r] == r + 1).all())
+                     for r in range(world))
         # (ii) stepping with the gathers overlapped (double-buffered fragments, asynchronous collective)
         ks = max(T, min(K, 4 * T) // T * T)
-        state["cur"] = 0
         fence()
         t1 = time.perf_counter()
-        run(ks, base=0, gather=True)
+        run(ks, gather=True)
         drain()
         fence()
         overl = maxed(time.perf_counter() - t1)
         gather_info = {"all_gather_ms_per_fragment": gather_ms, "fragment_steps": T,
                        "all_gather_bytes_per_rank_per_fragment": frags[0].nbytes(),
                        "env_steps_per_sec_with_overlapped_all_gather": world * n * ks / overl,
-                       "all_gather_algbw_GBps": world * frags[0].nbytes() / (gather_ms * 1e-3) / 1e9}
+                       "all_gather_algbw_GBps": world * frags[0].nbytes() / (gather_ms * 1e-3) / 1e9,
+                       "overlapped_gathers": state["gathers"], "gathered_content_ok": ok,
+                       "backend": dist.get_backend()}
 
     out = None
     if rank == 0:
@@ -326,17 +448,27 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": WORKLOADS[args.config] + "; trajectories written in place into [T=%d,N,...] fragments" % T +
                                       (" (their RCCL all-gather is reported separately in config.trajectory_all_gather)" if world > 1 else ""),
-                          "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": ("one k_step kernel launch per step (C ABI); %d of the %d timed steps enqueued as HIP graphs of %d launches "
-                                     "(qd_step_fragment), %d through per-step qd_step calls" % (timed_graph_steps, K, T, timed_call_steps)),
+                          "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "host_wait": host_wait, "frame_skip": 2 if args.config == "config2" else 1,
+                          "launch": ("one k_step kernel launch per step, issued through qd_step_fragment (C ABI): %d of the %d timed steps as "
+                                     "replayed HIP graphs (runs of >= %d steps, captured before the timed region), %d launch by launch"
+                                     % (timed_graph_steps, K, graph_min, timed_direct_steps)),
                           "precision": "float32 state / trigonometry / drag / integration, float64 inertia assembly and solves (load model)", "parallelism": "env-sharded x%d" % world,
                           "trajectory_all_gather": gather_info}}
-        # ---- roofline of the dominant kernel (k_step), measured live with HIP events -----------------
-        # average launch duration of k_step over the timed region: HIP events on the launch stream bracket the K
-        # back-to-back launches (the regen launches every 1024 steps are < 0.1 % of it), so elapsed / K is the
-        # kernel's average duration including the inter-kernel boundary -- the same quantity rocprofv3's kernel
-        # trace reports for back-to-back dispatches (profiles/r01_n4096_rocprof_summary.json)
-        kus = ev0.elapsed_time(ev1) * 1e3 / K
+        if args.dry:
+            out["dry_run"] = True
+            out["config"]["workload"] = "DRY RUN (CPU tensors, no env stepping, not a measurement): " + out["config"]["workload"]
+    if rank == 0 and not args.dry:
+        # ---- roofline of the dominant kernel (k_step), measured live with HIP events on the launch stream ----------------
+        # kernel_us = per-launch period of KERNEL_PERIOD_LAUNCHES back-to-back k_step launches (fixed length, whatever --steps
+        # is): the kernel's average duration incl. the inter-kernel boundary.  The same figure over the timed region itself
+        # (which for short runs is dominated by the launch from idle and the final synchronise) is reported beside it.
+        kus_timed = ev0.elapsed_time(ev1) * 1e3 / K
+        kfrag = par.FragmentBuffers(1024, n, D, device) if T != 1024 else frags[0]
+        if kfrag is not frags[0]:
+            kfrag.actions.copy_(lo + (hi - lo) * torch.rand(kfrag.actions.shape, generator=g, device=device, dtype=torch.float32))
+        kus, klaunches = kernel_period_us(env, kfrag)
+        P = 64
+        actions = kfrag.actions[:P]
         iso_us, raw_us, empty_us = kernel_time_us(env, actions)
         bytes_per_launch = ALG_BYTES[alg] * n
         achieved = bytes_per_launch / (kus * 1e-6) / 1e9
@@ -350,7 +482,11 @@ def main():
         copy_gbps = measured_copy_gbps(device)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
-                           "kernel_us": kus, "isolated_launch_us": iso_us, "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
+                           "kernel_us": kus,
+                           "kernel_us_source": "HIP events on the launch stream around %d back-to-back k_step launches (graph-replayed "
+                                               "1024-step fragments), independent of --steps" % klaunches,
+                           "timed_region_us_per_step": kus_timed, "isolated_launch_us": iso_us,
+                           "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
                            "env_steps_per_launch": n, "measured_copy_GBps": copy_gbps,
                            "frac_of_measured_copy": achieved / copy_gbps, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
                            "WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
@@ -359,13 +495,15 @@ def main():
         if not args.no_extras and world == 1:
             extras = {}
             try:
-                # the same K steps through the per-step Python API (vector_step_tensor): bound by the host launch path
+                step = env.vector_step_tensor if args.config != "config2" else env.step_tensor
+                # the same kind of steps through the per-step Python API (vector_step_tensor): bound by the host launch path
+                ksteps = max(K, 2048)
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
-                for t in range(K):
+                for t in range(ksteps):
                     step(actions[t % P])
                 torch.cuda.synchronize()
-                extras["per_step_api_env_steps_per_s"] = n * K / (time.perf_counter() - t1)
+                extras["per_step_api_env_steps_per_s"] = n * ksteps / (time.perf_counter() - t1)
                 sweep = []
                 for nn in (4096, 65536, 1048576, 4194304):
                     e2, alg2 = make_env(args.config, nn, 7, device)
@@ -400,88 +538,45 @@ def main():
                         e3._dev.rollout_pid(256)
                     torch.cuda.synchronize()
                     extras["pid_closed_loop_env_steps_per_s"] = 8 * 256 * n / (time.perf_counter() - t1)
-                # what the reference logs about a train batch (custom_logging.py:9-31, training.py:16-22), over the fragment the
-                # timed steps just wrote: per-column min / max / mean / var of obs and actions, episode returns / lengths
-                from mujoco_drone_amd.custom_logging import BatchStatistics, EpisodeStatistics
-                bs, es = BatchStatistics(), EpisodeStatistics(n, device)
-                f0 = frags[0]
-                for name, fn, nbytes in (("obs", lambda: bs.column_stats_tensor(f0.obs), f0.obs.numel() * 4),
-                                         ("actions", lambda: bs.column_stats_tensor(f0.actions), f0.actions.numel() * 4),
-                                         ("episodes", lambda: es.update_tensor(f0.rewards, f0.truncated), f0.rewards.numel() * 5)):
-                    for _ in range(3):
-                        fn()
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
-                    for _ in range(20):
-                        fn()
-                    ev1.record()
-                    torch.cuda.synchronize()
-                    us = ev0.elapsed_time(ev1) * 1000.0 / 20
-                    extras["fragment_%s_stats_us" % name] = us
-                    extras["fragment_%s_stats_GBps" % name] = nbytes / (us * 1e-6) / 1e9
                 if args.config == "config3":
                     # the reference's actor (RMA_full, train_PPO.py:39-45, random-init weights) inside the loop:
-                    # policy forward (f32 MFMA) -> env step, 2 launches per step enqueued by one C call, nothing leaves the GPU
+                    # policy forward (f32 MFMA) -> env step, nothing leaves the GPU
                     from mujoco_drone_amd.policy import DevicePolicy, random_weights
                     pol = DevicePolicy("RMA_full", random_weights("RMA_full", 3), device=device)
                     o3 = e3.vector_reset_tensor().clone()
                     pa = torch.empty((n, 4), device=device)
                     for _ in range(20):
                         pol.forward(o3, out=pa)
-                    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    ev0.record()
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
                     for _ in range(200):
                         pol.forward(o3, out=pa)
-                    ev1.record()
+                    e1.record()
                     torch.cuda.synchronize()
-                    extras["policy_forward_us"] = ev0.elapsed_time(ev1) * 1000.0 / 200
-                    extras["policy_forward_TFLOPs"] = 2 * 57792 * n / (extras["policy_forward_us"] * 1e-6) / 1e12
+                    extras["policy_forward_us"] = e0.elapsed_time(e1) * 1000.0 / 200
                     pol.rollout(e3._dev, 64, o3)
                     torch.cuda.synchronize()
                     t1 = time.perf_counter()
                     pol.rollout(e3._dev, 1024, o3)
                     torch.cuda.synchronize()
                     extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
-                    t1 = time.perf_counter()
-                    pol.rollout(e3._dev, 1024, o3, explore=True, seed=42, want_logp=True, want_value=True)
-                    torch.cuda.synchronize()
-                    extras["policy_sample_batch_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)  # sampled actions + logp + value
                     extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
-                    # train_RMA.py's network: RMA_full with the adaptation CNN over the 32-step history (incremental, per-env rings)
-                    pad = DevicePolicy("RMA_full_adapt", random_weights("RMA_full_adapt", 4), device=device)
-                    pad.reset_state(n)
-                    for k in range(20):
-                        pad.forward(o3, out=pa, counter=k)
-                    ev0.record()
-                    for k in range(200):
-                        pad.forward(o3, out=pa, counter=20 + k)
-                    ev1.record()
-                    torch.cuda.synchronize()
-                    extras["adapt_policy_forward_us"] = ev0.elapsed_time(ev1) * 1000.0 / 200
-                    pad.reset_state(n)
-                    pad.rollout(e3._dev, 64, o3)
-                    torch.cuda.synchronize()
-                    t1 = time.perf_counter()
-                    pad.rollout(e3._dev, 1024, o3, counter0=64)
-                    torch.cuda.synchronize()
-                    extras["adapt_policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
-                other = "config2" if args.config != "config2" else "config3"
-                e4, alg4 = make_env(other, n, 5, device)
-                (e4.vector_reset_tensor() if other == "config3" else e4.reset())
-                lo4, hi4 = (0.0, 1.0) if other == "config3" else (0.5, 1.0)
-                # like the headline: one kernel launch per step, the launches of a 1024-step fragment replayed from a HIP graph
-                a4 = lo4 + (hi4 - lo4) * torch.rand((1024, n, 4), device=device, dtype=torch.float32)
-                D4 = e4._dev.D
-                o4 = torch.empty((1024, n, D4), device=device); r4 = torch.empty((1024, n), device=device)
-                t4 = torch.empty((1024, n), dtype=torch.uint8, device=device)
-                for _ in range(2):
-                    e4.step_fragment_tensor(a4, o4, r4, t4)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for _ in range(4):
-                    e4.step_fragment_tensor(a4, o4, r4, t4)
-                torch.cuda.synchronize()
-                extras[other + "_env_steps_per_s"] = 4 * 1024 * n / (time.perf_counter() - t1)
+                for other in ("config2", "config3", "config5"):
+                    if other == args.config:
+                        continue
+                    n4 = 8192 if other == "config5" else n      # config 5 is quoted at 8192 envs per GPU
+                    e4, alg4 = make_env(other, n4, 5, device)
+                    (e4.reset() if other == "config2" else e4.vector_reset_tensor())
+                    lo4, hi4 = (0.5, 1.0) if other == "config2" else (0.0, 1.0)
+                    # like the headline: one kernel launch per step, the launches of a 1024-step fragment replayed from a HIP graph
+                    f4 = par.FragmentBuffers(1024, n4, e4._dev.D, device)
+                    f4.actions.copy_(lo4 + (hi4 - lo4) * torch.rand(f4.actions.shape, device=device, dtype=torch.float32))
+                    p4, _ = kernel_period_us(e4, f4)
+                    extras[other + "_env_steps_per_s"] = n4 / (p4 * 1e-6)
+                    extras[other + "_period_us"] = p4
+                    extras[other + "_envs"] = n4
+                    del e4, f4
+                    torch.cuda.empty_cache()
             except Exception as ex:  # extras never invalidate the headline line
                 extras["error"] = repr(ex)
             out["extras"] = extras

@@ -117,6 +117,14 @@ typedef struct qd_config {
 
 const char* qd_last_error(void);
 int         qd_version(void);
+/* SHA-256 (hex) over the sources this library was compiled from (the .hip / .h / .inc files of csrc and include/qd.h), as computed by
+ * mujoco-drone_amd/build.py: lets a host check that a prebuilt libqd.so matches the tree it sits in ("" if built by hand) */
+const char* qd_source_hash(void);
+/* How host threads wait for the device in hipStreamSynchronize / hipDeviceSynchronize on the CURRENT device:
+ * spin != 0 -> hipDeviceScheduleSpin (busy-wait: the wake-up after a short burst of step launches costs a few us instead
+ * of an interrupt round trip), 0 -> hipDeviceScheduleAuto.  A process-wide runtime setting, offered here because rollout
+ * loops of a few tens of 5-us steps are dominated by it; nothing in the env depends on it. */
+int qd_host_wait_spin(int spin);
 
 /* observation length D for (variant, model): observation_space.shape[0] as actually emitted */
 int    qd_obs_dim(int obs_kind, int model);
@@ -175,10 +183,12 @@ int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* senso
 int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
             uint8_t* truncated, void* stream);
 /* T consecutive qd_step launches (same kernels, same results: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N])
- * enqueued as ONE HIP graph: the first call with a given (T, buffers) captures the launches, later calls replay them, so
- * the per-step host launch path (~4-5 us, the bound of qd_step at 4096 envs) is paid once per fragment.  For rollout
- * fragments whose actions are already on the device (replays, or a policy that wrote the whole fragment).  The graph is
- * captured on a stream owned by the env and replayed in `stream`; qd_set_reference invalidates it. */
+ * issued by ONE call.  T < 128 (QD_GRAPH_MIN_STEPS): launch by launch from a C loop.  Otherwise as ONE HIP graph: the
+ * first call with a given (T, buffers) captures the launches, later calls replay them, so the per-step host launch path
+ * (~4-5 us, the bound of qd_step at 4096 envs) is paid once per fragment; up to 8 graphs are kept per env (least recently
+ * used replaced).  For rollout fragments whose actions are already on the device (replays, or a policy that wrote the
+ * whole fragment).  Graphs are captured on a stream owned by the env and replayed in `stream`; qd_set_reference
+ * invalidates them. */
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
 /* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
  * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */

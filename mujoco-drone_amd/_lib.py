@@ -6,6 +6,7 @@ there is no Python/CPU fallback for any of the calls below.
 import ctypes as C
 import os
 
+from . import build as _build
 from .build import LIB
 
 QD_OK, QD_ERR_INVALID, QD_ERR_SHAPE, QD_ERR_UNSUPPORTED, QD_ERR_HIP, QD_ERR_ARENA, QD_ERR_INDEX = 0, -1, -2, -3, -4, -5, -6
@@ -79,6 +80,8 @@ _D4 = C.POINTER(C.c_double)
 SIGNATURES = {
     "qd_last_error": (C.c_char_p, []),
     "qd_version": (_I, []),
+    "qd_source_hash": (C.c_char_p, []),
+    "qd_host_wait_spin": (_I, [_I]),
     "qd_obs_dim": (_I, [_I, _I]),
     "qd_state_dim": (_I, [_I]),
     "qd_arena_bytes": (C.c_size_t, [_I]),
@@ -148,6 +151,12 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the library does not export it
             fn.restype = res
             fn.argtypes = args
+        # a prebuilt library must come from exactly the sources beside it (QD_LIB = a diagnostic build, exempt)
+        if not os.environ.get("QD_LIB") and not os.environ.get("QD_ALLOW_STALE_LIB"):
+            have, want = handle.qd_source_hash().decode(), _build.source_hash(_build._extra_flags())
+            if have != want:
+                raise ImportError("libqd.so was built from other sources (library %s..., tree %s...): rebuild with "
+                                  "`python -m mujoco_drone_amd.build` or __graft_entry__.build()" % (have[:12], want[:12]))
         _lib = handle
     return _lib
 

@@ -2,18 +2,74 @@
 
 hipcc cross-compiles without a GPU, so this runs in the build container; the resulting
 .so travels to the GPU box with the repository snapshot.
+
+Staleness is decided by content, not by timestamps: the SHA-256 over every file the library is
+compiled from (csrc/*.hip, *.h, *.inc and include/qd.h -- discovered, not listed by hand) is
+compiled into the library (`qd_source_hash()`, also findable in the file as the text
+"QD_SOURCE_HASH=<hex>"), and `needs_build()` compares it with the sources as they are now.
+A prebuilt libqd.so that ships with a snapshot is therefore reused only if it was built from
+exactly these sources.
 """
+import glob
+import hashlib
 import os
+import re
 import shutil
 import subprocess
 import sys
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
+INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "include"))
 LIB = os.environ.get("QD_LIB") or os.path.join(PKG_DIR, "libqd.so")  # QD_LIB: diagnostic builds only
-SOURCES = ["qd_kernels.hip"]
-HEADERS = ["qd_math.h", "qd_model.h", "qd_dynamics.h", "qd_obsrew.h", "qd_rng.h", "qd_pid.h", "qd_stats.h", "qd_policy.h", "qd_policy_dist.h", "qd_policy_static.h", "qd_policy_host.inc", os.path.join("..", "..", "include", "qd.h")]
 ARCH = "gfx950"
+HASH_TAG = b"QD_SOURCE_HASH="
+
+
+def sources():
+    """translation units of the library"""
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+
+
+def dependencies():
+    """every file whose content reaches the compiler: the translation units, all headers / include fragments beside
+    them, and the public header"""
+    deps = set(sources())
+    for pat in ("*.h", "*.inc"):
+        deps.update(glob.glob(os.path.join(CSRC, pat)))
+    deps.update(glob.glob(os.path.join(INCLUDE, "*.h")))
+    return sorted(deps)
+
+
+def included_files(path):
+    """the quoted #include targets of one source file, resolved against its directory"""
+    text = open(path, encoding="utf-8").read()
+    return [os.path.normpath(os.path.join(os.path.dirname(path), m)) for m in re.findall(r'^\s*#\s*include\s+"([^"]+)"', text, re.M)]
+
+
+def source_hash(extra_flags=()):
+    h = hashlib.sha256()
+    for d in dependencies():
+        h.update(os.path.relpath(d, PKG_DIR).encode())
+        h.update(b"\0")
+        h.update(open(d, "rb").read())
+        h.update(b"\0")
+    h.update(" ".join(extra_flags).encode())
+    return h.hexdigest()
+
+
+def embedded_hash(lib_path=None):
+    """the source hash a built library carries (None if it has none or does not exist)"""
+    lib_path = lib_path or LIB
+    try:
+        blob = open(lib_path, "rb").read()
+    except OSError:
+        return None
+    k = blob.find(HASH_TAG)
+    if k < 0:
+        return None
+    hx = blob[k + len(HASH_TAG):k + len(HASH_TAG) + 64]
+    return hx.decode() if re.fullmatch(rb"[0-9a-f]{64}", hx) else None
 
 
 def _hipcc():
@@ -23,24 +79,31 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+def _extra_flags():
+    return tuple(os.environ.get("QD_EXTRA_HIPCC_FLAGS", "").split())
+
+
 def needs_build():
-    if not os.path.exists(LIB):
-        return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in SOURCES + HEADERS]
-    return any(os.path.getmtime(d) > t for d in deps)
+    return embedded_hash() != source_hash(_extra_flags())
 
 
 def build_library(force=False, verbose=False):
-    """Compile csrc/*.hip for gfx950 into libqd.so next to this file."""
+    """Compile csrc/*.hip for gfx950 into libqd.so next to this file (only if the sources changed, unless forced)."""
     if not force and not needs_build():
         return LIB
+    extra = _extra_flags()
+    tmp = LIB + ".tmp.%d" % os.getpid()
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc",
-           "-Wno-unused-result", "-o", LIB] + [os.path.join(CSRC, f) for f in SOURCES]
+           "-Wno-unused-result", '-DQD_SOURCE_HASH="%s"' % source_hash(extra), *extra, "-o", tmp] + sources()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), flush=True)
-    subprocess.check_call(cmd)
+    try:
+        subprocess.check_call(cmd)
+        os.replace(tmp, LIB)   # atomic: a process that has the old file mapped keeps its copy
+    finally:
+        if os.path.exists(tmp):
+            os.remove(tmp)
     return LIB
 
 

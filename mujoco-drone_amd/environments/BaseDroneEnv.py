@@ -465,14 +465,18 @@ class BaseDroneEnv(_VectorEnvBase):
 
     def step_fragment_tensor(self, actions, obs, reward, truncated):
         """T vector_steps (actions [T,N,4] already on the device) written in place into obs [T,N,D], reward [T,N],
-        truncated [T,N]: the per-step kernels replayed from a HIP graph.  The regen rule of vector_step is applied when the
-        fragment ends on the regen boundary; a fragment that would cross it falls back to step-by-step calls."""
+        truncated [T,N]: one k_step launch per step, issued by ONE C call (launch by launch below 128 steps, replayed from a
+        HIP graph above).  The regen rule of vector_step is applied when the fragment ends on the regen boundary; a fragment
+        that would cross it is cut there."""
         T = int(actions.shape[0])
         if self._reference is not self._ref_pushed:
             self._push_reference()
         if self._regen_at and self.total_steps + T > self._regen_at:
-            for t in range(T):
-                self.vector_step_tensor(actions[t], out=(obs[t], reward[t], truncated[t]))
+            cut = self._regen_at - self.total_steps
+            self.step_fragment_tensor(actions[:cut], obs[:cut], reward[:cut], truncated[:cut])
+            self.step_fragment_tensor(actions[cut:], obs[cut:], reward[cut:], truncated[cut:])
+            return obs, reward, truncated
+        if T == 0:
             return obs, reward, truncated
         self._dev.step_fragment(actions, obs, reward, truncated)
         self.total_steps += T
