@@ -73,82 +73,134 @@ QD_HD void fluid(T klin, T kang, T qlx, T qly, T qlz, T qax, T qay, T qaz, V3<T>
 
 template <class A, class B> QD_HD V3<A> cvt(V3<B> v) { return mk<A>(A(v.x), A(v.y), A(v.z)); }
 
-// forward dynamics at the current state.
-//   ex  : accelerations with damping explicit (what MuJoCo stores in qacc; feeds the sensor)
-//   im  : accelerations of the damping-implicit Euler update ((M + h D) a = M qacc)
-//   acc : accelerometer reading (site frame = body frame)
-template <class T, bool LOAD>
-QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Accel<T>* im, V3<T>* acc) {
-  using HP = typename HighPrec<T>::type;
-  // attitude (MuJoCo normalises the stored quaternion before use)
-  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-  const M3<T> R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
-  const V3<T> w = mk<T>(s.wx, s.wy, s.wz);
-  const V3<T> vb = mulT(R, mk<T>(s.vx, s.vy, s.vz));  // origin velocity in body axes
-  const T g = T(Const::gravity);
-  const V3<T> gt = mk<T>(g * R.m20, g * R.m21, g * R.m22);
+// solve with the LDL^T factor of the 3x3 rotational block (F: any struct with d0, d1, d2 = reciprocal pivots, l10, l20, l21)
+template <class F, class HP>
+QD_HD V3<HP> ldl_solve(const F& f, V3<HP> b) {
+  const HP y0 = b.x, y1 = b.y - f.l10 * y0;
+  const HP y2 = b.z - f.l20 * y0 - f.l21 * y1;
+  const HP z2 = y2 * f.d2;
+  const HP z1 = y1 * f.d1 - f.l21 * z2;
+  const HP z0 = y0 * f.d0 - f.l10 * z1 - f.l20 * z2;
+  return mk<HP>(z0, z1, z2);
+}
 
+// ---- the forward dynamics of the load model, in four pieces -----------------------------------------------
+// forward() below is their composition in one lane.  They are separate because the cooperative step kernel
+// (k_step_coop, qd_kernels.hip) runs them in three wavefronts of a workgroup at once: the applied wrench (thrust +
+// fluid drag, float32), the inertial wrench (gravity + velocity products, HP) and the mass-matrix factorisation (HP)
+// do not depend on each other, only the final solve needs all three.
+
+// attitude-dependent quantities shared by the pieces
+template <class T>
+struct Att {
+  M3<T> R;      // body -> world
+  V3<T> w;      // body-frame angular velocity
+  V3<T> vb;     // origin velocity in body axes
+  V3<T> gt;     // fictitious origin acceleration R^T (0,0,g)
+  V3<T> u;      // w x (w x zhat): velocity-product acceleration per unit height on the body z axis
+};
+template <class T>
+QD_HD Att<T> attitude(const State<T>& s) {
+  Att<T> a;
+  // MuJoCo normalises the stored quaternion before use
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+  a.R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
+  a.w = mk<T>(s.wx, s.wy, s.wz);
+  a.vb = mulT(a.R, mk<T>(s.vx, s.vy, s.vz));
+  const T g = T(Const::gravity);
+  a.gt = mk<T>(g * a.R.m20, g * a.R.m21, g * a.R.m22);
+  a.u = mk<T>(a.w.x * a.w.z, a.w.y * a.w.z, -(a.w.x * a.w.x + a.w.y * a.w.y));
+  return a;
+}
+// only the gravity direction and the angular velocity (what the inertial wrench needs of the attitude)
+template <class T>
+QD_HD void gravity_body(const State<T>& s, V3<T>* gt, V3<T>* w) {
+  const T qn2 = frcp(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);   // = qn * qn of attitude()
+  const T g2 = T(2) * T(Const::gravity) * qn2;
+  *gt = mk<T>(g2 * (s.qx * s.qz - s.qw * s.qy), g2 * (s.qy * s.qz + s.qw * s.qx), T(Const::gravity) - g2 * (s.qx * s.qx + s.qy * s.qy));
+  *w = mk<T>(s.wx, s.wy, s.wz);
+}
+
+// tether geometry from the two hinge angles (float32 trigonometry on the device)
+template <class T>
+struct Tether {
+  T s1, c1, s2, c2;
+  V3<T> d;     // unit vector anchor -> load (F0 axes)
+  V3<T> y2;    // hinge-2 axis (F0 axes); hinge-1 axis is x
+  V3<T> e_x;   // x axis of the tether frame F2 = Rx Ry (its z axis is -d)
+};
+template <class T>
+QD_HD Tether<T> tether_geometry(T th1, T th2) {
+  Tether<T> t;
+  qsincos(th1, &t.s1, &t.c1);
+  qsincos(th2, &t.s2, &t.c2);
+  t.d = mk<T>(-t.s2, t.s1 * t.c2, -t.c1 * t.c2);
+  t.y2 = mk<T>(T(0), t.c1, t.s1);
+  t.e_x = mk<T>(t.c2, t.s1 * t.s2, -t.c1 * t.s2);
+  return t;
+}
+
+// applied wrench: rotor thrust + inertia-box fluid drag on the three bodies, reduced to
+//   F  total force, Tq total torque about the body origin (both F0 axes), t1 / t2 hinge torques
+template <class T>
+struct Applied {
+  V3<T> F, Tq;
+  T t1, t2;
+};
+template <class T>
+QD_HD Applied<T> applied_wrench(const Model<T>& M, const State<T>& s, const Att<T>& at, const Tether<T>& tg) {
+  const V3<T> w = at.w, vb = at.vb;
   // rotors (env_gen.py:53-64): thrust along body z at (+-rot, +-rot, 0), yaw reaction +-gearT
   const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
   const V3<T> fT = mk<T>(T(0), T(0), f0 + f1 + f2 + f3);
   const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
-  // fluid drag on the core, evaluated in body axes (see qd_model.h on the principal frame);
-  // COM at (0,0,c0z): v_com = vb + w x c0
+  // fluid drag on the core, evaluated in body axes (see qd_model.h on the principal frame); COM at (0,0,c0z): v_com = vb + w x c0
   V3<T> fD0, tD0;
-  fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w,
-        mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
-  // u = w x (w x zhat): velocity-product acceleration per unit height on the body z axis
-  const V3<T> u = mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y));
-  const T sz = T(Const::sense_z);
+  fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w, mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
+  // fluid drag on link (frame F1 = Rx(th1)) and tether (frame F2)
+  const T az = T(Const::anchor_z), s1 = tg.s1, c1 = tg.c1;
+  const V3<T> d = tg.d, y2 = tg.y2, e_x = tg.e_x;
+  const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
+  const V3<T> w2 = w1 + s.thd2 * y2;
+  const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);  // anchor velocity
+  const V3<T> vc2 = va + M.lc * cross(w2, d);                      // tether COM velocity
+  const T k1 = T(LinkFluid::klin), k2 = T(LinkFluid::kang), k3 = T(LinkFluid::ql), k4 = T(LinkFluid::qa);
+  // F0 -> F1 components: Rx^T v = (x, c1 y + s1 z, -s1 y + c1 z)
+  V3<T> fl, tl;
+  fluid(k1, k2, k3, k3, k3, k4, k4, k4, mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z),
+        mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z), &fl, &tl);
+  const V3<T> fD1 = mk<T>(fl.x, c1 * fl.y - s1 * fl.z, s1 * fl.y + c1 * fl.z);
+  const V3<T> tD1 = mk<T>(tl.x, c1 * tl.y - s1 * tl.z, s1 * tl.y + c1 * tl.z);
+  fluid(M.klin2, M.kang2, M.qlt2, M.qlt2, M.qla2, M.qat2, M.qat2, M.qaa2,
+        mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2)), mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2)), &fl, &tl);
+  const V3<T> fD2 = fl.x * e_x + fl.y * y2 - fl.z * d;
+  const V3<T> tD2 = tl.x * e_x + tl.y * y2 - tl.z * d;
+  // reduction: wrench on the tether about the anchor, then everything about the origin
+  const V3<T> rho = M.lc * d;
+  const V3<T> t2v = tD2 + cross(rho, fD2);
+  const V3<T> f12 = fD1 + fD2;
+  Applied<T> ap;
+  ap.F = fT + fD0 + f12;
+  ap.Tq = tT + tD0 + mk<T>(-M.c0z * fD0.y, M.c0z * fD0.x, T(0)) + tD1 + mk<T>(-az * f12.y, az * f12.x, T(0)) + t2v;
+  ap.t1 = tD1.x + t2v.x;
+  ap.t2 = dot(y2, t2v);
+  return ap;
+}
 
-  if (!LOAD) {
-    // single rigid body: rotate about the COM, then recover the origin acceleration
-    const V3<T> ac0 = gt + M.c0z * u;
-    const V3<T> fl = fT + fD0 - M.m0 * ac0;
-    const V3<T> N0 = mk<T>(w.y * w.z * (M.I0z - M.I0y), w.z * w.x * (M.I0x - M.I0z), w.x * w.y * (M.I0y - M.I0x));
-    const V3<T> to = tT + tD0 - N0;  // c0 x thrust = 0 (both along z)
-    const V3<T> al = mk<T>(to.x * frcp(M.I0x), to.y * frcp(M.I0y), to.z * frcp(M.I0z));
-    const V3<T> a0 = frcp(M.m0) * fl - mk<T>(al.y * M.c0z, -al.x * M.c0z, T(0));
-    ex->lin = mul(R, a0); ex->ang = al; ex->thdd1 = ex->thdd2 = T(0);
-    *im = *ex;
-    *acc = a0 + gt + mk<T>(al.y * sz, -al.x * sz, T(0)) + sz * u;
-    return;
-  }
-
-  // ---- tether geometry (float32 trigonometry) -------------------------------------------
-  T s1, c1, s2, c2;
-  qsincos(s.th1, &s1, &c1);
-  qsincos(s.th2, &s2, &c2);
-  const T az = T(Const::anchor_z);
-  const V3<T> d = mk<T>(-s2, s1 * c2, -c1 * c2);   // unit vector anchor -> load (F0 axes)
-  const V3<T> y2 = mk<T>(T(0), c1, s1);            // hinge-2 axis (F0 axes); hinge-1 axis is x
-  const V3<T> e_x = mk<T>(c2, s1 * s2, -c1 * s2);  // x axis of the tether frame F2 = Rx Ry (its z axis is -d)
-
-  // ---- fluid drag on link (frame F1 = Rx(th1)) and tether (frame F2), float32 ------------
-  V3<T> fD1, tD1, fD2, tD2;
-  {
-    const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
-    const V3<T> w2 = w1 + s.thd2 * y2;
-    const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);  // anchor velocity
-    const V3<T> vc2 = va + M.lc * cross(w2, d);                      // tether COM velocity
-    const T k1 = T(LinkFluid::klin), k2 = T(LinkFluid::kang), k3 = T(LinkFluid::ql), k4 = T(LinkFluid::qa);
-    // F0 -> F1 components: Rx^T v = (x, c1 y + s1 z, -s1 y + c1 z)
-    V3<T> fl, tl;
-    fluid(k1, k2, k3, k3, k3, k4, k4, k4, mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z),
-          mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z), &fl, &tl);
-    fD1 = mk<T>(fl.x, c1 * fl.y - s1 * fl.z, s1 * fl.y + c1 * fl.z);
-    tD1 = mk<T>(tl.x, c1 * tl.y - s1 * tl.z, s1 * tl.y + c1 * tl.z);
-    fluid(M.klin2, M.kang2, M.qlt2, M.qlt2, M.qla2, M.qat2, M.qat2, M.qaa2,
-          mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2)), mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2)), &fl, &tl);
-    fD2 = fl.x * e_x + fl.y * y2 - fl.z * d;
-    tD2 = tl.x * e_x + tl.y * y2 - tl.z * d;
-  }
-
-  // ---- velocity-product terms and generalised forces, HP ---------------------------------
+// inertial wrench: the same reduction of mass x acceleration / Euler terms with all generalised accelerations zero
+// and origin acceleration g~ (gravity + velocity products), plus the passive hinge damping; HP arithmetic
+template <class HP>
+struct Inertial {
+  V3<HP> F, Tq;
+  HP t1, t2;
+};
+template <class T>
+QD_HD Inertial<typename HighPrec<T>::type> inertial_wrench(const Model<T>& M, const State<T>& s, V3<T> gt, V3<T> w, const Tether<T>& tg) {
+  using HP = typename HighPrec<T>::type;
   const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc;
   const HP c0z = M.c0z, azh = Const::anchor_z;
   const HP dI = HP(M.I2a) - It;
-  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt), dh = cvt<HP>(d), y2h = cvt<HP>(y2);
+  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt), dh = cvt<HP>(tg.d), y2h = cvt<HP>(tg.y2);
   const V3<HP> uh = mk<HP>(wh.x * wh.z, wh.y * wh.z, -(wh.x * wh.x + wh.y * wh.y));
   const HP thd1 = s.thd1, thd2 = s.thd2;
   const V3<HP> rho = lc * dh;                                         // anchor -> tether COM
@@ -159,7 +211,6 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
   const V3<HP> al1 = mk<HP>(HP(0), thd1 * wh.z, -thd1 * wh.y);        // thd1 * (w x xhat)
   const V3<HP> al2 = al1 + thd2 * cross(w1, y2h);
   const V3<HP> ac2 = aa + cross(al2, rho) + dot(w2, rho) * w2 - dot(w2, w2) * rho;
-  // inertial wrenches
   const V3<HP> F0 = m0 * (gth + c0z * uh);
   const V3<HP> N0 = mk<HP>(wh.y * wh.z * (HP(M.I0z) - HP(M.I0y)), wh.z * wh.x * (HP(M.I0x) - HP(M.I0z)),
                            wh.x * wh.y * (HP(M.I0y) - HP(M.I0x)));
@@ -167,24 +218,44 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
   const V3<HP> N1 = i1 * al1;
   const V3<HP> F2 = m2 * ac2;
   const V3<HP> N2 = It * al2 + (dI * dot(dh, al2)) * dh + (dI * dot(dh, w2)) * cross(w2, dh);
-  // applied minus inertial
-  const V3<HP> G0 = cvt<HP>(fD0) - F0, G1 = cvt<HP>(fD1) - F1, G2 = cvt<HP>(fD2) - F2;
-  const V3<HP> fl = cvt<HP>(fT) + G0 + G1 + G2;
-  const V3<HP> W2 = cvt<HP>(tD2) - N2 + cross(rho, G2);                // wrench on the tether about the anchor
-  const V3<HP> T1 = cvt<HP>(tD1) - N1;
-  const V3<HP> G12 = G1 + G2;
-  const V3<HP> fw = cvt<HP>(tT) + cvt<HP>(tD0) - N0 + mk<HP>(-c0z * G0.y, c0z * G0.x, HP(0)) + T1 +
-                    mk<HP>(-azh * G12.y, azh * G12.x, HP(0)) + W2;
+  const V3<HP> n2v = N2 + cross(rho, F2);
+  const V3<HP> F12 = F1 + F2;
   const HP bd = Const::damping;
-  const HP ft1 = T1.x + W2.x - bd * thd1;
-  const HP ft2 = dot(y2h, W2) - bd * thd2;
+  Inertial<HP> in;
+  in.F = F0 + F12;
+  in.Tq = N0 + mk<HP>(-c0z * F0.y, c0z * F0.x, HP(0)) + N1 + mk<HP>(-azh * F12.y, azh * F12.x, HP(0)) + n2v;
+  in.t1 = N1.x + n2v.x + bd * thd1;
+  in.t2 = dot(y2h, n2v) + bd * thd2;
+  return in;
+}
 
-  // ---- mass matrix about the system COM: sums of non-negative terms ------------------------
+// mass matrix about the system COM (sums of non-negative terms), LDL^T of its 3x3 rotational block, the two hinge
+// columns solved against it and the 2x2 Schur complement on the hinges; HP arithmetic
+template <class HP>
+struct Factor {
+  HP d0, d1, d2, l10, l20, l21;   // LDL^T (d = reciprocal pivots)
+  V3<HP> B1, B2, X1, X2;          // hinge columns of the mass matrix and J^-1 of them
+  HP s11, s12, s22;               // Schur complement (without the implicit damping h*b on its diagonal)
+  V3<HP> S, rc, p1, p2;           // first moment, COM, xhat x rho, y2 x rho
+  HP imt, m2;
+  // folded here so that the solve (the serial part of the step: everything waits for it) is as short as possible
+  V3<HP> Sm, kp1, kp2;            // imt * S, (m2 imt) * p1, (m2 imt) * p2
+  HP idet_ex, idet_im, hb;        // 1 / det of the Schur complement without / with the implicit damping hb on its diagonal
+};
+template <class T>
+QD_HD Factor<typename HighPrec<T>::type> mass_factor(const Model<T>& M, const Tether<T>& tg, T h) {
+  using HP = typename HighPrec<T>::type;
+  Factor<HP> f;
+  const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc;
+  const HP c0z = M.c0z, azh = Const::anchor_z;
+  const HP dI = HP(M.I2a) - It;
+  const V3<HP> dh = cvt<HP>(tg.d), y2h = cvt<HP>(tg.y2);
+  const V3<HP> rho = lc * dh;
   const HP mt = m0 + m1 + m2, imt = frcp(mt);
   const V3<HP> r2 = mk<HP>(rho.x, rho.y, rho.z + azh);
   const V3<HP> S = mk<HP>(m2 * r2.x, m2 * r2.y, m0 * c0z + m1 * azh + m2 * r2.z);
   const V3<HP> rc = imt * S;
-  const HP c1h = c1, s1h = s1, c2h = c2, s2h = s2;
+  const HP c1h = tg.c1, s1h = tg.s1, c2h = tg.c2, s2h = tg.s2;
   const V3<HP> p1 = lc * mk<HP>(HP(0), c1h * c2h, s1h * c2h);          // xhat x rho
   const V3<HP> p2 = lc * mk<HP>(-c2h, -s1h * s2h, c1h * s2h);          // y2 x rho
   const V3<HP> q2 = r2 - rc;
@@ -197,59 +268,113 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
   const HP Jxy = dI * dh.x * dh.y - m01 * qx * qy - m2 * q2.x * q2.y;
   const HP Jxz = dI * dh.x * dh.z - qx * z01 - m2 * q2.x * q2.z;
   const HP Jyz = dI * dh.y * dh.z - qy * z01 - m2 * q2.y * q2.z;
-  const V3<HP> B1 = mk<HP>(base, HP(0), HP(0)) + (dI * dh.x) * dh + m2 * cross(q2, p1);
-  const V3<HP> B2 = It * y2h + m2 * cross(q2, p2);
+  f.B1 = mk<HP>(base, HP(0), HP(0)) + (dI * dh.x) * dh + m2 * cross(q2, p1);
+  f.B2 = It * y2h + m2 * cross(q2, p2);
   const HP mu = m2 * (mt - m2) * imt;
   const HP lc2 = lc * lc;
   const HP D1 = base + dI * s2h * s2h + mu * lc2 * c2h * c2h;
   const HP D2 = It + mu * lc2;
-  const V3<HP> fwr = fw - cross(rc, fl);
+  // LDL^T of the 3x3 block
+  f.d0 = frcp(Jxx);
+  f.l10 = Jxy * f.d0; f.l20 = Jxz * f.d0;
+  f.d1 = frcp(Jyy - f.l10 * Jxy);
+  const HP t21 = Jyz - f.l20 * Jxy;
+  f.l21 = t21 * f.d1;
+  f.d2 = frcp(Jzz - f.l20 * Jxz - f.l21 * t21);
+  f.X1 = ldl_solve(f, f.B1);
+  f.X2 = ldl_solve(f, f.B2);
+  f.s11 = D1 - dot(f.B1, f.X1); f.s12 = -dot(f.B1, f.X2); f.s22 = D2 - dot(f.B2, f.X2);
+  f.S = S; f.rc = rc; f.p1 = p1; f.p2 = p2; f.imt = imt; f.m2 = m2;
   const HP k = m2 * imt;
-  const HP g1 = ft1 - k * dot(p1, fl);
-  const HP g2 = ft2 - k * dot(p2, fl);
+  f.Sm = imt * S; f.kp1 = k * p1; f.kp2 = k * p2;
+  f.hb = HP(h) * HP(Const::damping);
+  f.idet_ex = frcp(f.s11 * f.s22 - f.s12 * f.s12);
+  f.idet_im = frcp((f.s11 + f.hb) * (f.s22 + f.hb) - f.s12 * f.s12);
+  return f;
+}
 
-  // ---- LDL^T of the 3x3 block, three right-hand sides ----------------------------------------
-  const HP d0 = frcp(Jxx);
-  const HP l10 = Jxy * d0, l20 = Jxz * d0;
-  const HP d1 = frcp(Jyy - l10 * Jxy);
-  const HP t21 = Jyz - l20 * Jxy;
-  const HP l21 = t21 * d1;
-  const HP d2 = frcp(Jzz - l20 * Jxz - l21 * t21);
-#define QD_SOLVE3(b, o)                                       \
-  {                                                           \
-    const HP y0 = (b).x, y1 = (b).y - l10 * y0;               \
-    const HP y2_ = (b).z - l20 * y0 - l21 * y1;               \
-    const HP z2 = y2_ * d2;                                   \
-    const HP z1 = y1 * d1 - l21 * z2;                         \
-    const HP z0 = y0 * d0 - l10 * z1 - l20 * z2;              \
-    (o) = mk<HP>(z0, z1, z2);                                 \
+// right-hand side of the reduced system from the two wrenches
+template <class HP>
+struct Rhs {
+  V3<HP> fl, Xf;   // net force; J^-1 of the net torque about the COM
+  HP q1, q2;       // hinge right-hand sides after eliminating the rotational block
+};
+template <class T, class HP>
+QD_HD Rhs<HP> reduce_rhs(const Factor<HP>& f, const Applied<T>& ap, const Inertial<HP>& in) {
+  Rhs<HP> r;
+  r.fl = cvt<HP>(ap.F) - in.F;
+  const V3<HP> fw = cvt<HP>(ap.Tq) - in.Tq;
+  const HP ft1 = HP(ap.t1) - in.t1, ft2 = HP(ap.t2) - in.t2;
+  const V3<HP> fwr = fw - cross(f.rc, r.fl);
+  const HP g1 = ft1 - dot(f.kp1, r.fl);
+  const HP g2 = ft2 - dot(f.kp2, r.fl);
+  r.Xf = ldl_solve(f, fwr);
+  r.q1 = g1 - dot(f.B1, r.Xf);
+  r.q2 = g2 - dot(f.B2, r.Xf);
+  return r;
+}
+
+// generalised accelerations: IMPLICIT = false: damping explicit (what MuJoCo stores in qacc); true: the damping-implicit
+// Euler update (M + h D) a = M qacc, i.e. h * damping on the hinge diagonal.  a0 = origin acceleration in body axes.
+template <bool IMPLICIT, class T, class HP>
+QD_HD void finish_accel(const Factor<HP>& f, const Rhs<HP>& r, V3<HP>* a0, V3<T>* ang, T* thdd1, T* thdd2) {
+  const HP S11 = IMPLICIT ? f.s11 + f.hb : f.s11, S22 = IMPLICIT ? f.s22 + f.hb : f.s22;
+  const HP idet = IMPLICIT ? f.idet_im : f.idet_ex;
+  const HP t1 = (S22 * r.q1 - f.s12 * r.q2) * idet, t2 = (S11 * r.q2 - f.s12 * r.q1) * idet;
+  const V3<HP> al = r.Xf - t1 * f.X1 - t2 * f.X2;
+  *a0 = f.imt * r.fl - cross(al, f.Sm) - t1 * f.kp1 - t2 * f.kp2;
+  *ang = cvt<T>(al); *thdd1 = T(t1); *thdd2 = T(t2);
+}
+
+// accelerometer reading (site frame = body frame) from the damping-explicit accelerations
+template <class T>
+QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
+  const T sz = T(Const::sense_z);
+  return a0e + gt + mk<T>(ang_ex.y * sz, -ang_ex.x * sz, T(0)) + sz * u;
+}
+
+// forward dynamics at the current state.
+//   ex  : accelerations with damping explicit (what MuJoCo stores in qacc; feeds the sensor)
+//   im  : accelerations of the damping-implicit Euler update ((M + h D) a = M qacc)
+//   acc : accelerometer reading (site frame = body frame)
+template <class T, bool LOAD>
+QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Accel<T>* im, V3<T>* acc) {
+  using HP = typename HighPrec<T>::type;
+  const Att<T> at = attitude(s);
+  if (!LOAD) {
+    const M3<T>& R = at.R;
+    const V3<T> w = at.w, vb = at.vb, gt = at.gt, u = at.u;
+    const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
+    const V3<T> fT = mk<T>(T(0), T(0), f0 + f1 + f2 + f3);
+    const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
+    V3<T> fD0, tD0;
+    fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w,
+          mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
+    const T sz = T(Const::sense_z);
+    // single rigid body: rotate about the COM, then recover the origin acceleration
+    const V3<T> ac0 = gt + M.c0z * u;
+    const V3<T> fl = fT + fD0 - M.m0 * ac0;
+    const V3<T> N0 = mk<T>(w.y * w.z * (M.I0z - M.I0y), w.z * w.x * (M.I0x - M.I0z), w.x * w.y * (M.I0y - M.I0x));
+    const V3<T> to = tT + tD0 - N0;  // c0 x thrust = 0 (both along z)
+    const V3<T> al = mk<T>(to.x * frcp(M.I0x), to.y * frcp(M.I0y), to.z * frcp(M.I0z));
+    const V3<T> a0 = frcp(M.m0) * fl - mk<T>(al.y * M.c0z, -al.x * M.c0z, T(0));
+    ex->lin = mul(R, a0); ex->ang = al; ex->thdd1 = ex->thdd2 = T(0);
+    *im = *ex;
+    *acc = a0 + gt + mk<T>(al.y * sz, -al.x * sz, T(0)) + sz * u;
+    return;
   }
-  V3<HP> Xf, X1, X2;
-  QD_SOLVE3(fwr, Xf);
-  QD_SOLVE3(B1, X1);
-  QD_SOLVE3(B2, X2);
-#undef QD_SOLVE3
-  // 2x2 Schur complement on the hinges
-  const HP s11 = D1 - dot(B1, X1), s12 = -dot(B1, X2), s22 = D2 - dot(B2, X2);
-  const HP q1 = g1 - dot(B1, Xf), q2s = g2 - dot(B2, Xf);
-  const HP hb = HP(h) * bd;
-  V3<HP> a0ex;
-#define QD_FINISH(S11, S22, out, A0)                                                     \
-  {                                                                                      \
-    const HP idet = frcp((S11) * (S22) - s12 * s12);                                     \
-    const HP t1 = ((S22) * q1 - s12 * q2s) * idet, t2 = ((S11) * q2s - s12 * q1) * idet; \
-    const V3<HP> al = Xf - t1 * X1 - t2 * X2;                                            \
-    A0 = imt * (fl - cross(al, S) - (m2 * t1) * p1 - (m2 * t2) * p2);                    \
-    (out)->ang = cvt<T>(al); (out)->thdd1 = T(t1); (out)->thdd2 = T(t2);                 \
-  }
-  V3<HP> a0im;
-  QD_FINISH(s11, s22, ex, a0ex);
-  QD_FINISH(s11 + hb, s22 + hb, im, a0im);
-#undef QD_FINISH
+  const Tether<T> tg = tether_geometry(s.th1, s.th2);
+  const Applied<T> ap = applied_wrench(M, s, at, tg);
+  const Inertial<HP> in = inertial_wrench(M, s, at.gt, at.w, tg);
+  const Factor<HP> f = mass_factor(M, tg, h);
+  const Rhs<HP> r = reduce_rhs(f, ap, in);
+  V3<HP> a0ex, a0im;
+  finish_accel<false>(f, r, &a0ex, &ex->ang, &ex->thdd1, &ex->thdd2);
+  finish_accel<true>(f, r, &a0im, &im->ang, &im->thdd1, &im->thdd2);
   const V3<T> a0e = cvt<T>(a0ex);
-  *acc = a0e + gt + mk<T>(ex->ang.y * sz, -ex->ang.x * sz, T(0)) + sz * u;
-  ex->lin = mul(R, a0e);
-  im->lin = mul(R, cvt<T>(a0im));
+  *acc = accelerometer(a0e, ex->ang, at.gt, at.u);
+  ex->lin = mul(at.R, a0e);
+  im->lin = mul(at.R, cvt<T>(a0im));
 }
 
 // Euler advance of one substep with the accelerations `im`: activations, velocities, then positions with the NEW velocities

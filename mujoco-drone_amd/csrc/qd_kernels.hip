@@ -10,8 +10,9 @@
 //   ACC  (accelerometer xyz, -)                 M0..M6 derived model constants (qd_model.h)
 //   P0   (mass, arm_len, motor_force, motor_tau) P1 (pendulum_len, weight_mass, -, -)
 //   REF  (x,y,z,yaw) per-env reference (only read when per_env_reference is set)
-//   NX0..NX4 the pre-sampled initial state of the env's NEXT episode: (pos,th1) (quat) (vel,th2) (angvel,thd1)
-//        (thd2, episode tag:u32, valid:u32, -), see "reset pool" below
+//   NX0..NX4 / NY0..NY4 the pre-sampled initial states of the env's next two episodes (even / odd episode counter):
+//        (pos,th1) (quat) (vel,th2) (angvel,thd1) (thd2, episode tag:u32, valid:u32, -), see "reset pool" below
+// behind the planes: RAW x 6 float64 planes, then one uint32 per 64 envs: refill requests of the reset pool
 // Observations are produced row-major [N,D] (what the policy network consumes); a
 // wavefront's 64 rows are one contiguous 64*D*4-byte span, so rows are staged through LDS
 // and written back with full-width coalesced stores.
@@ -40,7 +41,8 @@ namespace qd {
 
 enum Group {
   G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_M4, G_M5, G_M6, G_P0, G_P1, G_REF,
-  G_NX0, G_NX1, G_NX2, G_NX3, G_NX4,  // pre-sampled initial state of each env's next episode (filled by sampler waves)
+  G_NX0, G_NX1, G_NX2, G_NX3, G_NX4,  // reset pool, slot 0: pre-sampled initial state of the env's episodes with an EVEN counter
+  G_NY0, G_NY1, G_NY2, G_NY3, G_NY4,  //             slot 1: ... with an ODD counter (filled by sampler waves, see "reset pool")
   G_C0, G_C1, G_C2, G_C3,             // memory of the analytic PID cascade (qd_pid.h); touched only by the qd_pid_* entry points
   NUM_GROUPS
 };
@@ -50,6 +52,7 @@ constexpr int PAD = 256;
 struct KArgs {
   float4* g;
   double* raw;
+  uint32_t* need;     // [npad / 64] reset-pool refill requests, one counter per 64 consecutive envs
   int npad, n;
   float ref[4];
   int per_env_ref;
@@ -79,6 +82,11 @@ struct EnvRegs {  // everything one lane keeps in registers for one env
   uint32_t flags;  // FLAG_ACC_STALE: the stored accelerometer value predates an in-kernel reset
 };
 constexpr uint32_t FLAG_ACC_STALE = 1u;
+
+// one lane asks for a refill of its env's reset-pool entries (see "reset pool"; the counter covers the lane's 64-env group)
+__device__ __forceinline__ void pool_request(const KArgs& a, int i) {
+  __hip_atomic_fetch_add(a.need + (i >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 
 // Compile-time specialisations of the fused step for the configurations the reference trains with; every other
 // configuration runs the generic instantiation, which dispatches on the KArgs fields at run time (wave-uniform
@@ -183,6 +191,17 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
   }
 }
 
+// everything of store_env but the accelerometer plane
+__device__ __forceinline__ void store_env_state(const KArgs& a, int i, const EnvRegs& e) {
+  float4* g = a.g;
+  const int np = a.npad;
+  g[G_POS * np + i] = make_float4(e.s.px, e.s.py, e.s.pz, e.s.th1);
+  g[G_QUAT * np + i] = make_float4(e.s.qw, e.s.qx, e.s.qy, e.s.qz);
+  g[G_VEL * np + i] = make_float4(e.s.vx, e.s.vy, e.s.vz, e.s.th2);
+  g[G_ANG * np + i] = make_float4(e.s.wx, e.s.wy, e.s.wz, e.s.thd1);
+  g[G_ACT * np + i] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
+  g[G_AUX * np + i] = make_float4(e.s.thd2, __int_as_float(e.num_steps), __uint_as_float(e.episode), __uint_as_float(e.flags));
+}
 __device__ __forceinline__ void store_env(const KArgs& a, int i, const EnvRegs& e) {
   float4* g = a.g;
   const int np = a.npad;
@@ -206,13 +225,54 @@ __device__ __forceinline__ void refresh_sensor(const KArgs& a, EnvRegs& e) {
 // the initial state of episode `episode` of env i (positions, attitude, velocities, hinges; NOT the activations)
 template <bool LOAD>
 __device__ __forceinline__ void sample_episode(const KArgs& a, int i, uint32_t episode, State<float>& s) {
-  if (a.sc.random_start == QD_START_SIMPLE) {
+  if (!LOAD && a.sc.random_start == QD_START_SIMPLE) {   // SimpleDrone.reset_model: the no-load model only (qd_create enforces it)
     sample_simple(a.sc, a.seed, (uint32_t)i, (uint32_t)a.n, episode, s);
   } else {
     float z[16], u[2];
     sample_draws(a.seed, (uint32_t)i, episode, z, u);
     sample_state<LOAD>(a.sc, z, u, s);
   }
+}
+
+// ---- reset pool ------------------------------------------------------------------------------
+// Drawing a new initial state costs ~1000 instructions (5 Philox blocks, 8 Box-Muller pairs, the
+// transforms).  Done inline by the lanes that truncate, it sits on the critical path of their
+// wavefront -- and with 4096 envs and ~150-step episodes a third of the 64 wavefronts contain such a
+// lane every step, so the whole launch waits for it.  Instead the step kernels are launched with extra
+// "sampler" workgroups (on CUs the physics waves leave idle) that keep the initial state of each env's
+// NEXT episode ready in the arena: episode e lives in slot e & 1 (planes NX* / NY*); a truncating lane only
+// loads its entry.  The sample for (env, episode) is a pure function of the Philox counter, so results do
+// not depend on who computes it or when.  Protocol (no intra-launch synchronisation):
+//   explicit reset (k_reset)  : draws episode e inline, and leaves sample(e+1) in its slot for the new counter e+1
+//   sampler, any step launch  : if need[w] == 0 for its 64 envs -> exit.  Otherwise, with E = AUX.episode as it reads it,
+//                               makes slot (E+1) & 1 hold sample(E+1) and subtracts the request count it had read
+//   physics, on truncation    : in episode e, if slot e & 1 is valid with tag e -> take it, mark it consumed and add 1
+//                               to need[w]; otherwise (never filled, pool off) sample inline.
+// A sampler only ever writes the slot of the episode AFTER the counter it reads, a lane only reads the slot of its
+// counter at launch start, and it stores a new counter after it is done reading: the slot a lane may read is never the
+// one a sampler of the same launch writes.  An entry is therefore complete one kernel boundary before it can be read --
+// no fence, and its planes may be fetched in any order and ahead of time (k_step_coop).  A lost race costs speed only:
+// a request counted twice re-checks 64 tags, an entry that is not there is sampled inline.
+__device__ __forceinline__ int pool_slot(uint32_t episode) { return (episode & 1u) ? (int)G_NY0 : (int)G_NX0; }
+
+__device__ __forceinline__ void pool_store(const KArgs& a, int i, uint32_t episode, const State<float>& s) {
+  float4* g = a.g;
+  const int np = a.npad, base = pool_slot(episode);
+  g[(base + 0) * np + i] = make_float4(s.px, s.py, s.pz, s.th1);
+  g[(base + 1) * np + i] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  g[(base + 2) * np + i] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  g[(base + 3) * np + i] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  g[(base + 4) * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(1u), 0.f);
+}
+
+// make the slot of episode `next` hold its sample (no-op if it already does)
+template <bool LOAD>
+__device__ __forceinline__ void pool_fill(const KArgs& a, int i, uint32_t next) {
+  const float4 nx4 = a.g[(pool_slot(next) + 4) * a.npad + i];
+  if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == next) return;
+  State<float> s;
+  sample_episode<LOAD>(a, i, next, s);
+  pool_store(a, i, next, s);
 }
 
 // sample_state for this lane's env, episode counter advanced.  eager_sensor: run mj_forward's sensor
@@ -223,40 +283,29 @@ __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e, bool
   sample_episode<LOAD>(a, i, e.episode, e.s);
   e.episode += 1u;
   e.num_steps = 0;
+  if (a.use_pool) pool_fill<LOAD>(a, i, e.episode);   // the new counter's own entry: samplers only ever fill the one after it
   if (eager_sensor) refresh_sensor<LOAD>(a, e);
   else e.flags |= FLAG_ACC_STALE;
 }
 
-// ---- reset pool ------------------------------------------------------------------------------
-// Drawing a new initial state costs ~1000 instructions (5 Philox blocks, 8 Box-Muller pairs, the
-// transforms).  Done inline by the lanes that truncate, it sits on the critical path of their
-// wavefront -- and with 4096 envs and ~150-step episodes a third of the 64 wavefronts contain such a
-// lane every step, so the whole launch waits for it.  Instead k_step is launched with TWICE the
-// workgroups: the second half ("sampler" workgroups, on CUs the 64 physics waves leave idle) keeps
-// one pre-sampled initial state per env ready in the NX planes; a truncating lane only loads it.
-// The sample for (env, episode) is a pure function of the Philox counter, so results do not depend
-// on who computes it or when.  Protocol (no intra-launch synchronisation needed):
-//   sampler, launch k  : if NX4.valid == 0 or NX4.tag != AUX.episode -> write sample(AUX.episode), tag, valid = 1
-//   physics, launch k+1: on truncation, if NX4.valid and NX4.tag == episode -> take it, NX4.valid = 0;
-//                        otherwise (pool not refilled yet, explicit reset in between) sample inline.
-// An entry is consumed at the earliest one launch after it was written (kernel boundary = visibility).
+// body of a sampler wavefront: its 64 lanes serve the envs [j0, j0 + 64) of one refill counter
 template <bool LOAD>
-__device__ __forceinline__ void pool_fill(const KArgs& a, int i) {
-  float4* g = a.g;
-  const int np = a.npad;
-  const float4 nx4 = g[G_NX4 * np + i];
-  const uint32_t episode = __float_as_uint(g[G_AUX * np + i].z);
-  if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == episode) return;
-  State<float> s;
-  sample_episode<LOAD>(a, i, episode, s);
-  g[G_NX0 * np + i] = make_float4(s.px, s.py, s.pz, s.th1);
-  g[G_NX1 * np + i] = make_float4(s.qw, s.qx, s.qy, s.qz);
-  g[G_NX2 * np + i] = make_float4(s.vx, s.vy, s.vz, s.th2);
-  g[G_NX3 * np + i] = make_float4(s.wx, s.wy, s.wz, s.thd1);
-  // the tag goes last and after a release fence: an env lane of the same launch that sees it valid must see the four planes above
-  // (it reads them only after the tag, through a branch, so its side needs no fence)
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-  g[G_NX4 * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(1u), 0.f);
+__device__ __forceinline__ void sampler_wave(const KArgs& a, int j) {
+  const int w = j >> 6;
+  if ((w << 6) >= a.n) return;
+  const uint32_t pending = __hip_atomic_load(a.need + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (pending == 0u) return;
+  if (j < a.n) pool_fill<LOAD>(a, j, __float_as_uint(a.g[G_AUX * a.npad + j].z) + 1u);
+  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_sub(a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// what a reset does to everything but the sampled state (shared by the single-wave and the cooperative step)
+__device__ __forceinline__ void reset_bookkeeping(State<float>& s, uint32_t& episode, int& num_steps) {
+  // activations survive a reset (reference quirk C-2) -- unless they diverged: MuJoCo's bad-state check would have
+  // called mj_resetData, which zeroes them
+  if (!(fabsf(s.a0) + fabsf(s.a1) + fabsf(s.a2) + fabsf(s.a3) < 1e10f)) s.a0 = s.a1 = s.a2 = s.a3 = 0.f;
+  episode += 1u;
+  num_steps = 0;
 }
 
 // reset of a truncated lane inside the step kernel: pool entry if it is there, inline sampling otherwise
@@ -265,25 +314,22 @@ __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e)
   bool taken = false;
   if (a.use_pool) {
     float4* g = a.g;
-    const int np = a.npad;
-    const float4 nx4 = g[G_NX4 * np + i];
+    const int np = a.npad, base = pool_slot(e.episode);
+    const float4 nx4 = g[(base + 4) * np + i];
     if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == e.episode) {
-      const float4 p = g[G_NX0 * np + i], q = g[G_NX1 * np + i], v = g[G_NX2 * np + i], w = g[G_NX3 * np + i];
+      const float4 p = g[(base + 0) * np + i], q = g[(base + 1) * np + i], v = g[(base + 2) * np + i], w = g[(base + 3) * np + i];
       e.s.px = p.x; e.s.py = p.y; e.s.pz = p.z; e.s.th1 = p.w;
-      e.s.qw = q.x; e.s.qx = q.y; e.s.qy = q.z; e.s.qz = q.w;
+      e.s.qw = q.x; e.s.qy = q.z; e.s.qx = q.y; e.s.qz = q.w;
       e.s.vx = v.x; e.s.vy = v.y; e.s.vz = v.z; e.s.th2 = v.w;
       e.s.wx = w.x; e.s.wy = w.y; e.s.wz = w.z; e.s.thd1 = w.w;
       e.s.thd2 = nx4.x;
-      g[G_NX4 * np + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
+      g[(base + 4) * np + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
       taken = true;
     }
+    pool_request(a, i);
   }
   if (!taken) sample_episode<LOAD>(a, i, e.episode, e.s);
-  // activations survive a reset (reference quirk C-2) -- unless they diverged: MuJoCo's bad-state check would have
-  // called mj_resetData, which zeroes them
-  if (!(fabsf(e.s.a0) + fabsf(e.s.a1) + fabsf(e.s.a2) + fabsf(e.s.a3) < 1e10f)) e.s.a0 = e.s.a1 = e.s.a2 = e.s.a3 = 0.f;
-  e.episode += 1u;
-  e.num_steps = 0;
+  reset_bookkeeping(e.s, e.episode, e.num_steps);
   if (a.obs_needs_acc) refresh_sensor<LOAD>(a, e);
   else e.flags |= FLAG_ACC_STALE;
 }
@@ -379,8 +425,19 @@ __device__ unsigned long long qd_rstamps[64 * 2];
     __builtin_amdgcn_sched_barrier(0);                                                                \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_stamps[blockIdx.x * 8 + (k)] = t_;           \
   } while (0)
+// cooperative step: 12 stamps per (workgroup, wave)
+__device__ unsigned long long qd_cstamps[64 * 3 * 12];
+#define QD_CSTAMP(k)                                                                                        \
+  do {                                                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    unsigned long long t_;                                                                                  \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                      \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_cstamps[(blockIdx.x * 3 + role) * 12 + (k)] = t_;   \
+  } while (0)
 #else
 #define QD_STAMP(k)
+#define QD_CSTAMP(k)
 #endif
 
 // ---- one full env step for the lane's env (everything after the state is in registers) ----
@@ -445,8 +502,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
   if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
-    const int j = ((int)blockIdx.x - a.main_blocks) * BLOCK + threadIdx.x;
-    if (j < a.n) pool_fill<LOAD>(a, j);
+    sampler_wave<LOAD>(a, ((int)blockIdx.x - a.main_blocks) * BLOCK + threadIdx.x);
     return;
   }
   const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -485,6 +541,276 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   QD_STAMP(7);
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_rstamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
+#endif
+}
+
+// ---- cooperative step: THREE wavefronts per 64 envs ------------------------------------------------------------
+// At 4096 envs the single-wave step is a latency chain: one wavefront alone on its SIMD issues one vector instruction
+// per 4 cycles, so its ~1300 instructions ARE the kernel time (3 of the 5 us period), while 94 % of the chip idles.
+// The load model's forward dynamics has three mutually independent parts of similar length -- the applied wrench
+// (thrust + drag on three bodies, float32), the inertial wrench (gravity + velocity products, float64) and the
+// mass-matrix factorisation (float64), qd_dynamics.h -- and so has the epilogue (reward / state stores, attitude half
+// of the observation row, position half of it).  k_step_coop runs them in three wavefronts of one workgroup (three
+// SIMDs of a CU), lane l of each wave working on env l of the group, exchanging 16 + 16 + 24 dwords per env through
+// LDS at three workgroup barriers:
+//   wave A: mass_factor                 | reduce_rhs, finish_accel(im), integrate, truncation, (reset) | finish_accel(ex),
+//                                       |                                                               accelerometer, reward, stores
+//   wave B: attitude, applied_wrench    | -                                                            | roll / pitch / hinge / param slots
+//   wave C: inertial_wrench, pool entry | -                                                            | frame-dependent slots (e_l, heading, v_l)
+// Same arithmetic as the single-wave step (the same functions, composed across waves instead of in one lane).
+constexpr int COOP_THREADS = 192;
+struct CoopLds {
+  float4 app[5][64];     // B -> A: Applied (F, t1) (Tq, t2) and the attitude matrix (9 values)
+  double2 ine[4][64];    // C -> A: Inertial (F, Tq, t1, t2)
+  float4 nxt[5][64];     // C -> A: the env's reset-pool entry for its current episode counter, as stored (prefetched)
+  float4 st[2][6][64];   // A -> B, C: [0] the state after the step, [1] after the in-kernel reset (truncated lanes only):
+                         //   (pos, th1) (quat) (vel, th2) (angvel, thd1) (act) (thd2, accelerometer)
+  uint32_t flag[64];     // A -> B, C: the lane was reset (its observation row is the new episode's first)
+  float tile[64 * 24];   // the group's observation rows, row-major like the global span
+};
+// observation slots whose value depends on the attitude matrix / yaw (wave C); the rest are wave B's
+template <int SPEC> constexpr unsigned coop_frame_slots() { return 0x1E7u; }  // e_l 0..2, heading 5, v_l 6..8 (RPY_PARAMS and FULLSTATE)
+
+// Workgroup barrier for an LDS hand-over: waits for this wave's LDS operations only.  __syncthreads() also drains the wave's
+// global stores and atomics (vmcnt(0)) -- a ~1300-cycle round trip whenever wave A has just consumed a pool entry.
+__device__ __forceinline__ void coop_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+__device__ __forceinline__ void coop_put_state(CoopLds& L, int set, int lane, const State<float>& s, V3<float> acc) {
+  L.st[set][0][lane] = make_float4(s.px, s.py, s.pz, s.th1);
+  L.st[set][1][lane] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  L.st[set][2][lane] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  L.st[set][3][lane] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  L.st[set][4][lane] = make_float4(s.a0, s.a1, s.a2, s.a3);
+  L.st[set][5][lane] = make_float4(s.thd2, acc.x, acc.y, acc.z);
+}
+__device__ __forceinline__ void coop_get_state(const CoopLds& L, int set, int lane, State<float>& s, V3<float>& acc) {
+  const float4 p = L.st[set][0][lane], q = L.st[set][1][lane], v = L.st[set][2][lane], w = L.st[set][3][lane];
+  const float4 c = L.st[set][4][lane], x = L.st[set][5][lane];
+  s.px = p.x; s.py = p.y; s.pz = p.z; s.th1 = p.w;
+  s.qw = q.x; s.qx = q.y; s.qy = q.z; s.qz = q.w;
+  s.vx = v.x; s.vy = v.y; s.vz = v.z; s.th2 = v.w;
+  s.wx = w.x; s.wy = w.y; s.wz = w.z; s.thd1 = w.w;
+  s.a0 = c.x; s.a1 = c.y; s.a2 = c.z; s.a3 = c.w;
+  s.thd2 = x.x; acc = mk<float>(x.y, x.z, x.w);
+}
+
+// one wave's share of the observation row: FRAME = the slots that need the attitude matrix / yaw (wave C), else the rest (wave B).
+// Both instantiate the full observe<>() of the variant; what a wave does not store is dead code for it.
+template <int SPEC, bool FRAME>
+__device__ __forceinline__ void coop_obs_part(const KArgs& a, int i, int lane, const EnvRegs& e, CoopLds& L) {
+  constexpr int D = spec_obs_dim<SPEC>();
+  constexpr int KIND = SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : (int)OBS_FULLSTATE;
+  constexpr unsigned MASK = coop_frame_slots<SPEC>();
+  const bool rst = L.flag[lane] != 0u;
+  State<float> s;
+  V3<float> sacc;
+  coop_get_state(L, rst ? 1 : 0, lane, s, sacc);
+  float ref[4] = {e.ref[0], e.ref[1], e.ref[2], e.ref[3]};
+  if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ref);
+  float sv[33], o[QD_MAX_OBS];
+  M3<float> Rq;
+  drone_state<float, true>(s, sacc, ref, e.par, sv, &Rq);
+  observe<float, 33, KIND>(sv, ref, o, &Rq);
+  float* row = L.tile + lane * D;
+#pragma unroll
+  for (int k = 0; k < D; k++)
+    if ((((MASK >> k) & 1u) != 0u) == FRAME) row[k] = o[k];
+}
+
+template <int SPEC>
+__global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+                                                            float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
+  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM, "cooperative step: the load model's training configurations");
+  constexpr int D = spec_obs_dim<SPEC>();
+  constexpr int KIND = SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : (int)OBS_FULLSTATE;
+  constexpr bool OBS_ACC = SPEC == SPEC_LSTM;   // the observation row carries the accelerometer reading
+  __shared__ CoopLds L;
+  if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
+    sampler_wave<true>(a, ((int)blockIdx.x - a.main_blocks) * COOP_THREADS + threadIdx.x);
+    return;
+  }
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int i = blockIdx.x * 64 + lane;
+  const bool live = i < a.n;
+  QD_CSTAMP(0);
+  // every wave fetches its env's planes (what a role does not use is a dead load); non-live lanes only keep the barriers company
+  EnvRegs e;
+  float4 action = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (live) {
+    load_env<true, false, false>(a, i, e);
+    action = reinterpret_cast<const float4*>(actions)[i];
+  }
+  Factor<double> f;
+#ifdef QD_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+  QD_CSTAMP(1);
+  // ---------------------------------------------------------------- phase 1: three independent parts
+  if (live) {
+    const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
+    if (role == 0) {
+      f = mass_factor(e.M, tg, a.h);
+    } else if (role == 1) {
+      const Att<float> at = attitude(e.s);
+      const Applied<float> ap = applied_wrench(e.M, e.s, at, tg);
+      L.app[0][lane] = make_float4(ap.F.x, ap.F.y, ap.F.z, ap.t1);
+      L.app[1][lane] = make_float4(ap.Tq.x, ap.Tq.y, ap.Tq.z, ap.t2);
+      L.app[2][lane] = make_float4(at.R.m00, at.R.m01, at.R.m02, at.R.m10);
+      L.app[3][lane] = make_float4(at.R.m11, at.R.m12, at.R.m20, at.R.m21);
+      L.app[4][lane] = make_float4(at.R.m22, 0.f, 0.f, 0.f);
+    } else {
+      // the pool entry the env would take if it truncates in this step: requested first, stored last
+      float4 nx[5];
+      if (a.use_pool && a.auto_reset) {
+        const int base = pool_slot(e.episode);
+#pragma unroll
+        for (int k = 0; k < 5; k++) nx[k] = a.g[(base + k) * a.npad + i];
+      } else {
+#pragma unroll
+        for (int k = 0; k < 5; k++) nx[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      V3<float> gt, w;
+      gravity_body(e.s, &gt, &w);
+      const Inertial<double> in = inertial_wrench(e.M, e.s, gt, w, tg);
+      L.ine[0][lane] = make_double2(in.F.x, in.F.y);
+      L.ine[1][lane] = make_double2(in.F.z, in.Tq.x);
+      L.ine[2][lane] = make_double2(in.Tq.y, in.Tq.z);
+      L.ine[3][lane] = make_double2(in.t1, in.t2);
+#pragma unroll
+      for (int k = 0; k < 5; k++) L.nxt[k][lane] = nx[k];
+    }
+  }
+  QD_CSTAMP(2);
+  coop_barrier();
+  QD_CSTAMP(3);
+  // ---------------------------------------------------------------- phase 2 (wave A): solve, integrate, truncation, reset
+  Rhs<double> r;
+  M3<float> R;
+  V3<float> w0 = mk<float>(0.f, 0.f, 0.f), acc = mk<float>(0.f, 0.f, 0.f);
+  State<float> post;   // the state the reward is computed from (after the step, before a reset)
+  int steps_post = 0;
+  bool tr = false;
+  if (role == 0 && live) {
+    float c0 = qclamp(0.1f + 0.9f * action.x, 0.f, 1.f), c1 = qclamp(0.1f + 0.9f * action.y, 0.f, 1.f);
+    float c2 = qclamp(0.1f + 0.9f * action.z, 0.f, 1.f), c3 = qclamp(0.1f + 0.9f * action.w, 0.f, 1.f);
+    Applied<float> ap;
+    {
+      const float4 x0 = L.app[0][lane], x1 = L.app[1][lane], x2 = L.app[2][lane], x3 = L.app[3][lane], x4 = L.app[4][lane];
+      ap.F = mk<float>(x0.x, x0.y, x0.z); ap.t1 = x0.w;
+      ap.Tq = mk<float>(x1.x, x1.y, x1.z); ap.t2 = x1.w;
+      R.m00 = x2.x; R.m01 = x2.y; R.m02 = x2.z; R.m10 = x2.w; R.m11 = x3.x; R.m12 = x3.y; R.m20 = x3.z; R.m21 = x3.w; R.m22 = x4.x;
+    }
+    Inertial<double> in;
+    {
+      const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
+      in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
+    }
+    r = reduce_rhs(f, ap, in);
+    Accel<float> im;
+    V3<double> a0im;
+    finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+    im.lin = mul(R, cvt<float>(a0im));
+    w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
+    if (OBS_ACC) {  // the row needs this step's reading: damping-explicit accelerations before the hand-over
+      Accel<float> ex;
+      V3<double> a0ex;
+      finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+      const float g = float(Const::gravity);
+      acc = accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                          mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+      e.acc = acc;
+    }
+    integrate<float, true>(e.M, e.s, im, c0, c1, c2, c3, a.h);
+    e.flags &= ~FLAG_ACC_STALE;
+    e.num_steps += 1;
+    steps_post = e.num_steps;
+    post = e.s;
+    {  // default_termination_fcn on the position alone (the same test truncated() makes on the state vector)
+      const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+      tr = !(qsqrt(dx * dx + dy * dy + dz * dz) <= a.max_distance) || e.num_steps >= a.max_steps;
+    }
+    coop_put_state(L, 0, lane, e.s, acc);
+    const bool rst = a.auto_reset && tr;
+    bool taken = false;
+    float4 nx4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rst) {
+      State<float> ns;   // the new episode's state; the activations carry over (reset_bookkeeping)
+      if (a.use_pool) {
+        nx4 = L.nxt[4][lane];
+        taken = __float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == e.episode;
+      }
+      if (taken) {
+        const float4 p = L.nxt[0][lane], q = L.nxt[1][lane], v = L.nxt[2][lane], w = L.nxt[3][lane];
+        ns.px = p.x; ns.py = p.y; ns.pz = p.z; ns.th1 = p.w;
+        ns.qw = q.x; ns.qx = q.y; ns.qy = q.z; ns.qz = q.w;
+        ns.vx = v.x; ns.vy = v.y; ns.vz = v.z; ns.th2 = v.w;
+        ns.wx = w.x; ns.wy = w.y; ns.wz = w.z; ns.thd1 = w.w;
+        ns.thd2 = nx4.x;
+      } else {
+        sample_episode<true>(a, i, e.episode, ns);
+      }
+      ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
+      e.s = ns;
+      const uint32_t consumed = e.episode;
+      reset_bookkeeping(e.s, e.episode, e.num_steps);
+      if (OBS_ACC) refresh_sensor<true>(a, e);   // the new episode's first row reads the sensor at the new state
+      else e.flags |= FLAG_ACC_STALE;
+      coop_put_state(L, 1, lane, e.s, e.acc);
+      // global side effects last: nothing in this phase waits behind them (memory operations retire in order)
+      if (a.use_pool) {
+        if (taken) a.g[(pool_slot(consumed) + 4) * a.npad + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
+        pool_request(a, i);
+      }
+    }
+    L.flag[lane] = rst ? 1u : 0u;
+  }
+  QD_CSTAMP(4);
+  coop_barrier();
+  QD_CSTAMP(5);
+  // ---------------------------------------------------------------- phase 3: epilogue, split three ways
+  if (live) {
+    if (role == 0) {
+      store_env_state(a, i, e);   // positions / velocities / activations / counters: on their way while the rest is computed
+      if (!OBS_ACC) {
+        Accel<float> ex;
+        V3<double> a0ex;
+        finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+        const float g = float(Const::gravity);
+        acc = accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                            mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+        e.acc = acc;   // stored even when a reset marked it stale: it is this step's reading (single-wave step: same)
+      }
+      a.g[G_ACC * a.npad + i] = make_float4(e.acc.x, e.acc.y, e.acc.z, 0.f);
+      float sv[33];
+      M3<float> Rq;
+      const float act4[4] = {action.x, action.y, action.z, action.w};
+      drone_state<float, true>(post, acc, e.ref, e.par, sv, &Rq);
+      const float rw = reward<float>(spec_reward<SPEC>(a), sv, act4, steps_post, e.ref, a.max_distance, &Rq);
+      __builtin_nontemporal_store(rw, reward_out + i);
+      __builtin_nontemporal_store((uint8_t)(tr ? 1 : 0), trunc_out + i);
+    } else if (role == 1) {
+      coop_obs_part<SPEC, false>(a, i, lane, e, L);
+    } else {
+      coop_obs_part<SPEC, true>(a, i, lane, e, L);
+    }
+  }
+  QD_CSTAMP(6);
+  coop_barrier();
+  QD_CSTAMP(7);
+  {  // the group's rows are one contiguous span: 16-byte streaming stores by all three waves
+    const int base_env = blockIdx.x * 64;
+    const int rows = min(64, a.n - base_env);
+    const int total = rows * D, n4 = total >> 2;
+    const float4* t4 = reinterpret_cast<const float4*>(L.tile);
+    float4* d4 = reinterpret_cast<float4*>(obs + (size_t)base_env * D);
+    for (int j = threadIdx.x; j < n4; j += COOP_THREADS) store_streaming(d4 + j, t4[j]);
+    for (int j = (n4 << 2) + threadIdx.x; j < total; j += COOP_THREADS) __builtin_nontemporal_store(L.tile[j], obs + (size_t)base_env * D + j);
+  }
+  QD_CSTAMP(8);
+#ifdef QD_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  QD_CSTAMP(9);
 #endif
 }
 
@@ -807,6 +1133,8 @@ __global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
     g[G_AUX * np + i] = make_float4(0.f, __int_as_float(0), __uint_as_float(0u), 0.f);
     g[G_REF * np + i] = make_float4(a.ref[0], a.ref[1], a.ref[2], a.ref[3]);
     g[G_NX4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+    g[G_NY4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
+    if ((i & 63) == 0) a.need[i >> 6] = 1u;   // empty pool: the first step launch's samplers fill it
     PidState<float> c;
     pid_reset(c);
     store_pid(a, i, c);
@@ -1042,6 +1370,12 @@ static int qd_graph_min_steps() {
   static const int v = [] { const char* e = getenv("QD_GRAPH_MIN_STEPS"); return e ? atoi(e) : 128; }();
   return v;
 }
+// largest batch stepped by the three-wave cooperative kernel (3 waves per 64 envs must find idle SIMDs: 16384 envs = 768
+// waves on 1024 SIMDs); QD_COOP_MAX_ENVS overrides it (0 switches the kernel off)
+static int qd_coop_max_envs() {
+  static const int v = [] { const char* e = getenv("QD_COOP_MAX_ENVS"); return e ? atoi(e) : 16384; }();
+  return v;
+}
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
 extern "C" {
@@ -1065,6 +1399,9 @@ int qd_debug_read_stamps(unsigned long long* out_host) {
 int qd_debug_read_pstamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd::qd_pstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
+int qd_debug_read_cstamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_cstamps), sizeof(unsigned long long) * 64 * 3 * 12) == hipSuccess ? 0 : -4;
+}
 int qd_debug_read_rstamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_rstamps), sizeof(unsigned long long) * 64 * 2) == hipSuccess ? 0 : -4;
 }
@@ -1082,7 +1419,7 @@ static inline int npad_of(int n) { return (n + PAD - 1) / PAD * PAD; }
 size_t qd_arena_bytes(int num_envs) {
   if (num_envs <= 0) return 0;
   const size_t np = (size_t)npad_of(num_envs);
-  return np * ((size_t)NUM_GROUPS * sizeof(float4) + (size_t)RAW_PLANES * sizeof(double));
+  return np * ((size_t)NUM_GROUPS * sizeof(float4) + (size_t)RAW_PLANES * sizeof(double)) + (np / 64) * sizeof(uint32_t);
 }
 
 static int needs_load_reward(int k) {
@@ -1106,6 +1443,8 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   if ((c->obs_kind == QD_OBS_SIMPLE) != (c->term_kind == QD_TERM_SIMPLE))
     return fail(QD_ERR_INVALID, "the SimpleDrone observation and the SimpleDrone termination rule go together");
   if (c->random_start < 0 || c->random_start > QD_START_SIMPLE) return fail(QD_ERR_INVALID, "unknown random_start %d", c->random_start);
+  if (c->random_start == QD_START_SIMPLE && c->model != QD_MODEL_NOLOAD)
+    return fail(QD_ERR_UNSUPPORTED, "QD_START_SIMPLE is SimpleDrone.reset_model: it exists for the no-load model only");
   if (c->frame_skip < 1) return fail(QD_ERR_INVALID, "frame_skip must be >= 1");
   if (!(c->timestep > 0)) return fail(QD_ERR_INVALID, "timestep must be positive");
   if (!arena) return fail(QD_ERR_ARENA, "null arena");
@@ -1123,6 +1462,7 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.npad = npad_of(c->num_envs);
   k.g = reinterpret_cast<float4*>(arena);
   k.raw = reinterpret_cast<double*>(k.g + (size_t)NUM_GROUPS * k.npad);
+  k.need = reinterpret_cast<uint32_t*>(k.raw + (size_t)RAW_PLANES * k.npad);
   for (int i = 0; i < 4; i++) k.ref[i] = (float)c->reference[i];
   k.per_env_ref = c->per_env_reference;
   k.h = (float)c->timestep;
@@ -1342,7 +1682,14 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
       else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
     }                                                                        \
   } while (0)
-  if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(256);
+  if (env->load && (env->spec == SPEC_RMA || env->spec == SPEC_LSTM) && k.n <= qd_coop_max_envs()) {
+    // small batches of the training configurations: three wavefronts per 64 envs (k_step_coop)
+    KArgs kk = k;
+    kk.main_blocks = blocks64(k.n);
+    const dim3 grid(kk.main_blocks + (k.use_pool ? (k.n + COOP_THREADS - 1) / COOP_THREADS : 0));
+    if (env->spec == SPEC_RMA) QD_LAUNCH((k_step_coop<SPEC_RMA>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
+    else QD_LAUNCH((k_step_coop<SPEC_LSTM>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
+  } else if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(256);
   else QD_STEP_BLOCK(64);
 #undef QD_STEP_BLOCK
 #undef QD_STEP_LAUNCH

@@ -20,6 +20,11 @@ except AttributeError:  # pragma: no cover
         return torch.cuda.current_stream(index).cuda_stream
 
 
+# float4 planes of the arena, in the order of `enum Group` in csrc/qd_kernels.hip (tests/test_host_logic.py keeps the two in step)
+ARENA_PLANES = ["POS", "QUAT", "VEL", "ANG", "ACT", "AUX", "ACC", "M0", "M1", "M2", "M3", "M4", "M5", "M6", "P0", "P1", "REF",
+                "NX0", "NX1", "NX2", "NX3", "NX4", "NY0", "NY1", "NY2", "NY3", "NY4", "C0", "C1", "C2", "C3"]
+
+
 class DeviceEnv:
     def __init__(self, cfg: L.QdConfig, device="cuda:0"):
         self.lib = L.lib()  # raises if libqd.so is missing: no CPU path
@@ -196,11 +201,15 @@ class DeviceEnv:
         L.check(self.lib.qd_drone_states(self.handle, _ptr(out), self._stream()))
         return out
 
+    def planes(self):
+        """the arena's float4 planes as a [len(ARENA_PLANES), N, 4] float32 view (diagnostics and tests)"""
+        npad = (self.n + 255) // 256 * 256
+        ngroups = len(ARENA_PLANES)
+        return self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
+
     def model_constants(self):
         """per-env derived model constants (qd_model.h), read straight from the arena planes"""
-        npad = (self.n + 255) // 256 * 256
-        ngroups, first = 26, 7  # plane layout of csrc/qd_kernels.hip: M0..M6 are planes 7..13
-        g = self.arena[:ngroups * npad * 16].view(torch.float32).view(ngroups, npad, 4)[:, :self.n]
+        g, first = self.planes(), ARENA_PLANES.index("M0")
         names = ["m0", "c0z", "I0x", "I0y", "I0z", "rot", "gearF", "gearT", "inv_tau", "m2", "lc", "I2t", "I2a", "klin0",
                  "kang0", "qlx0", "qly0", "qlz0", "qax0", "qay0", "qaz0", "klin2", "kang2", "qlt2", "qla2", "qat2", "qaa2"]
         flat = torch.cat([g[first + k] for k in range(7)], dim=1)

@@ -1,9 +1,12 @@
 """Host-side mirror of the reference interface: config keys, class and function names, selection of device
 kernels by name, loud failure without a GPU.  No GPU needed."""
 import json
+import os
 
 import numpy as np
 import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_base_config_equals_reference(golden):
@@ -155,3 +158,14 @@ def test_load_policy_state_reads_rllib_checkpoint_layout(tmp_path):
     st = load_policy_state(str(tmp_path))
     assert st["global_timestep"] == 7 and np.array_equal(st["weights"]["_logits.0._model.0.weight"], w["_logits.0._model.0.weight"])
     assert callable(evaluate_trajectory_lstmest)
+
+
+def test_arena_plane_table_matches_the_kernel_source():
+    """environments/_device.py names the arena's float4 planes; the order must be the `enum Group` of csrc/qd_kernels.hip"""
+    import re
+    from mujoco_drone_amd.environments._device import ARENA_PLANES
+    src = open(os.path.join(ROOT, "mujoco-drone_amd", "csrc", "qd_kernels.hip")).read()
+    body = re.search(r"enum Group \{(.*?)NUM_GROUPS", src, re.S).group(1)
+    body = re.sub(r"//[^\n]*", "", body)
+    names = [m.replace("G_", "") for m in re.findall(r"\b(G_[A-Z0-9]+)\b", body)]
+    assert names == ARENA_PLANES
