@@ -270,7 +270,6 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     n, K, W, T = args.envs, args.steps, args.warmup, args.fragment
-    host_wait = "runtime default"
     if args.dry:
         device, env, alg, D = "cpu", None, {"config3": "load22", "config2": "noload6", "config5": "load23"}[args.config], OBS_DIM[args.config]
     else:
@@ -279,13 +278,6 @@ def main():
             local = 0
         torch.cuda.set_device(local)
         device = "cuda:%d" % local
-        torch.zeros(1, device=device)            # the device's runtime state exists before its wait mode is set
-        if not os.environ.get("QD_BENCH_NO_SPIN"):
-            # host threads busy-wait in synchronize (hipDeviceScheduleSpin): a timed region of 20 five-microsecond steps
-            # should not end with an interrupt round trip; reported in config.host_wait
-            from mujoco_drone_amd import _lib as L_
-            L_.check(L_.lib().qd_host_wait_spin(1))
-            host_wait = "spin (hipDeviceScheduleSpin)"
         env, alg = make_env(args.config, n, par.shard_seed(42, rank), device)
         if args.config != "config2":
             env.vector_reset_tensor()
@@ -448,7 +440,7 @@ def main():
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": WORKLOADS[args.config] + "; trajectories written in place into [T=%d,N,...] fragments" % T +
                                       (" (their RCCL all-gather is reported separately in config.trajectory_all_gather)" if world > 1 else ""),
-                          "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "host_wait": host_wait, "frame_skip": 2 if args.config == "config2" else 1,
+                          "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "frame_skip": 2 if args.config == "config2" else 1,
                           "launch": ("one k_step kernel launch per step, issued through qd_step_fragment (C ABI): %d of the %d timed steps as "
                                      "replayed HIP graphs (runs of >= %d steps, captured before the timed region), %d launch by launch"
                                      % (timed_graph_steps, K, graph_min, timed_direct_steps)),

@@ -120,11 +120,6 @@ int         qd_version(void);
 /* SHA-256 (hex) over the sources this library was compiled from (the .hip / .h / .inc files of csrc and include/qd.h), as computed by
  * mujoco-drone_amd/build.py: lets a host check that a prebuilt libqd.so matches the tree it sits in ("" if built by hand) */
 const char* qd_source_hash(void);
-/* How host threads wait for the device in hipStreamSynchronize / hipDeviceSynchronize on the CURRENT device:
- * spin != 0 -> hipDeviceScheduleSpin (busy-wait: the wake-up after a short burst of step launches costs a few us instead
- * of an interrupt round trip), 0 -> hipDeviceScheduleAuto.  A process-wide runtime setting, offered here because rollout
- * loops of a few tens of 5-us steps are dominated by it; nothing in the env depends on it. */
-int qd_host_wait_spin(int spin);
 
 /* observation length D for (variant, model): observation_space.shape[0] as actually emitted */
 int    qd_obs_dim(int obs_kind, int model);

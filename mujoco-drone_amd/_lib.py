@@ -81,7 +81,6 @@ SIGNATURES = {
     "qd_last_error": (C.c_char_p, []),
     "qd_version": (_I, []),
     "qd_source_hash": (C.c_char_p, []),
-    "qd_host_wait_spin": (_I, [_I]),
     "qd_obs_dim": (_I, [_I, _I]),
     "qd_state_dim": (_I, [_I]),
     "qd_arena_bytes": (C.c_size_t, [_I]),

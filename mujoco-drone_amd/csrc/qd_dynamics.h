@@ -242,7 +242,9 @@ struct Factor {
   V3<HP> Sm, kp1, kp2;            // imt * S, (m2 imt) * p1, (m2 imt) * p2
   HP idet_ex, idet_im, hb;        // 1 / det of the Schur complement without / with the implicit damping hb on its diagonal
 };
-template <class T>
+// PRE: also fold the products and reciprocals the solve needs (cooperative kernel: the factorisation has slack, the solve
+// does not); without it they are formed where they are used, which keeps fewer values alive (single-lane composition)
+template <bool PRE = true, class T>
 QD_HD Factor<typename HighPrec<T>::type> mass_factor(const Model<T>& M, const Tether<T>& tg, T h) {
   using HP = typename HighPrec<T>::type;
   Factor<HP> f;
@@ -285,11 +287,13 @@ QD_HD Factor<typename HighPrec<T>::type> mass_factor(const Model<T>& M, const Te
   f.X2 = ldl_solve(f, f.B2);
   f.s11 = D1 - dot(f.B1, f.X1); f.s12 = -dot(f.B1, f.X2); f.s22 = D2 - dot(f.B2, f.X2);
   f.S = S; f.rc = rc; f.p1 = p1; f.p2 = p2; f.imt = imt; f.m2 = m2;
-  const HP k = m2 * imt;
-  f.Sm = imt * S; f.kp1 = k * p1; f.kp2 = k * p2;
   f.hb = HP(h) * HP(Const::damping);
-  f.idet_ex = frcp(f.s11 * f.s22 - f.s12 * f.s12);
-  f.idet_im = frcp((f.s11 + f.hb) * (f.s22 + f.hb) - f.s12 * f.s12);
+  if (PRE) {
+    const HP k = m2 * imt;
+    f.Sm = imt * S; f.kp1 = k * p1; f.kp2 = k * p2;
+    f.idet_ex = frcp(f.s11 * f.s22 - f.s12 * f.s12);
+    f.idet_im = frcp((f.s11 + f.hb) * (f.s22 + f.hb) - f.s12 * f.s12);
+  }
   return f;
 }
 
@@ -299,15 +303,16 @@ struct Rhs {
   V3<HP> fl, Xf;   // net force; J^-1 of the net torque about the COM
   HP q1, q2;       // hinge right-hand sides after eliminating the rotational block
 };
-template <class T, class HP>
+template <bool PRE = true, class T, class HP>
 QD_HD Rhs<HP> reduce_rhs(const Factor<HP>& f, const Applied<T>& ap, const Inertial<HP>& in) {
   Rhs<HP> r;
   r.fl = cvt<HP>(ap.F) - in.F;
   const V3<HP> fw = cvt<HP>(ap.Tq) - in.Tq;
   const HP ft1 = HP(ap.t1) - in.t1, ft2 = HP(ap.t2) - in.t2;
   const V3<HP> fwr = fw - cross(f.rc, r.fl);
-  const HP g1 = ft1 - dot(f.kp1, r.fl);
-  const HP g2 = ft2 - dot(f.kp2, r.fl);
+  const HP k = f.m2 * f.imt;
+  const HP g1 = PRE ? ft1 - dot(f.kp1, r.fl) : ft1 - k * dot(f.p1, r.fl);
+  const HP g2 = PRE ? ft2 - dot(f.kp2, r.fl) : ft2 - k * dot(f.p2, r.fl);
   r.Xf = ldl_solve(f, fwr);
   r.q1 = g1 - dot(f.B1, r.Xf);
   r.q2 = g2 - dot(f.B2, r.Xf);
@@ -316,13 +321,14 @@ QD_HD Rhs<HP> reduce_rhs(const Factor<HP>& f, const Applied<T>& ap, const Inerti
 
 // generalised accelerations: IMPLICIT = false: damping explicit (what MuJoCo stores in qacc); true: the damping-implicit
 // Euler update (M + h D) a = M qacc, i.e. h * damping on the hinge diagonal.  a0 = origin acceleration in body axes.
-template <bool IMPLICIT, class T, class HP>
+template <bool IMPLICIT, bool PRE = true, class T, class HP>
 QD_HD void finish_accel(const Factor<HP>& f, const Rhs<HP>& r, V3<HP>* a0, V3<T>* ang, T* thdd1, T* thdd2) {
   const HP S11 = IMPLICIT ? f.s11 + f.hb : f.s11, S22 = IMPLICIT ? f.s22 + f.hb : f.s22;
-  const HP idet = IMPLICIT ? f.idet_im : f.idet_ex;
+  const HP idet = PRE ? (IMPLICIT ? f.idet_im : f.idet_ex) : frcp(S11 * S22 - f.s12 * f.s12);
   const HP t1 = (S22 * r.q1 - f.s12 * r.q2) * idet, t2 = (S11 * r.q2 - f.s12 * r.q1) * idet;
   const V3<HP> al = r.Xf - t1 * f.X1 - t2 * f.X2;
-  *a0 = f.imt * r.fl - cross(al, f.Sm) - t1 * f.kp1 - t2 * f.kp2;
+  if (PRE) *a0 = f.imt * r.fl - cross(al, f.Sm) - t1 * f.kp1 - t2 * f.kp2;
+  else *a0 = f.imt * (r.fl - cross(al, f.S) - (f.m2 * t1) * f.p1 - (f.m2 * t2) * f.p2);
   *ang = cvt<T>(al); *thdd1 = T(t1); *thdd2 = T(t2);
 }
 
@@ -333,6 +339,30 @@ QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
   return a0e + gt + mk<T>(ang_ex.y * sz, -ang_ex.x * sz, T(0)) + sz * u;
 }
 
+// The same forward dynamics as forward() below, composed from the pieces above in one lane (load model).  The step
+// kernels do NOT use it: hipcc schedules the monolithic forward() with fewer live values (36 vs 52 bytes of scratch in the
+// 256-thread instantiation, 12-16 % of the step time in the HBM-bound regime), so forward() stays as it was and the pieces
+// serve the cooperative kernel.  tests/test_host_twin.py holds the two together: identical to 1e-12 in float64.
+template <class T>
+QD_HD void forward_pieces(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Accel<T>* im, V3<T>* acc) {
+  using HP = typename HighPrec<T>::type;
+  const Att<T> at = attitude(s);
+  const Tether<T> tg = tether_geometry(s.th1, s.th2);
+  const Applied<T> ap = applied_wrench(M, s, at, tg);
+  V3<T> gt, w;
+  gravity_body(s, &gt, &w);
+  const Inertial<HP> in = inertial_wrench(M, s, gt, w, tg);
+  const Factor<HP> f = mass_factor<true>(M, tg, h);
+  const Rhs<HP> r = reduce_rhs<true>(f, ap, in);
+  V3<HP> a0ex, a0im;
+  finish_accel<false, true>(f, r, &a0ex, &ex->ang, &ex->thdd1, &ex->thdd2);
+  finish_accel<true, true>(f, r, &a0im, &im->ang, &im->thdd1, &im->thdd2);
+  const V3<T> a0e = cvt<T>(a0ex);
+  *acc = accelerometer(a0e, ex->ang, at.gt, at.u);
+  ex->lin = mul(at.R, a0e);
+  im->lin = mul(at.R, cvt<T>(a0im));
+}
+
 // forward dynamics at the current state.
 //   ex  : accelerations with damping explicit (what MuJoCo stores in qacc; feeds the sensor)
 //   im  : accelerations of the damping-implicit Euler update ((M + h D) a = M qacc)
@@ -340,17 +370,28 @@ QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
 template <class T, bool LOAD>
 QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Accel<T>* im, V3<T>* acc) {
   using HP = typename HighPrec<T>::type;
-  const Att<T> at = attitude(s);
+  // attitude (MuJoCo normalises the stored quaternion before use)
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+  const M3<T> R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
+  const V3<T> w = mk<T>(s.wx, s.wy, s.wz);
+  const V3<T> vb = mulT(R, mk<T>(s.vx, s.vy, s.vz));  // origin velocity in body axes
+  const T g = T(Const::gravity);
+  const V3<T> gt = mk<T>(g * R.m20, g * R.m21, g * R.m22);
+
+  // rotors (env_gen.py:53-64): thrust along body z at (+-rot, +-rot, 0), yaw reaction +-gearT
+  const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
+  const V3<T> fT = mk<T>(T(0), T(0), f0 + f1 + f2 + f3);
+  const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
+  // fluid drag on the core, evaluated in body axes (see qd_model.h on the principal frame);
+  // COM at (0,0,c0z): v_com = vb + w x c0
+  V3<T> fD0, tD0;
+  fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w,
+        mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
+  // u = w x (w x zhat): velocity-product acceleration per unit height on the body z axis
+  const V3<T> u = mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y));
+  const T sz = T(Const::sense_z);
+
   if (!LOAD) {
-    const M3<T>& R = at.R;
-    const V3<T> w = at.w, vb = at.vb, gt = at.gt, u = at.u;
-    const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
-    const V3<T> fT = mk<T>(T(0), T(0), f0 + f1 + f2 + f3);
-    const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
-    V3<T> fD0, tD0;
-    fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w,
-          mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
-    const T sz = T(Const::sense_z);
     // single rigid body: rotate about the COM, then recover the origin acceleration
     const V3<T> ac0 = gt + M.c0z * u;
     const V3<T> fl = fT + fD0 - M.m0 * ac0;
@@ -363,18 +404,142 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
     *acc = a0 + gt + mk<T>(al.y * sz, -al.x * sz, T(0)) + sz * u;
     return;
   }
-  const Tether<T> tg = tether_geometry(s.th1, s.th2);
-  const Applied<T> ap = applied_wrench(M, s, at, tg);
-  const Inertial<HP> in = inertial_wrench(M, s, at.gt, at.w, tg);
-  const Factor<HP> f = mass_factor(M, tg, h);
-  const Rhs<HP> r = reduce_rhs(f, ap, in);
-  V3<HP> a0ex, a0im;
-  finish_accel<false>(f, r, &a0ex, &ex->ang, &ex->thdd1, &ex->thdd2);
-  finish_accel<true>(f, r, &a0im, &im->ang, &im->thdd1, &im->thdd2);
+
+  // ---- tether geometry (float32 trigonometry) -------------------------------------------
+  T s1, c1, s2, c2;
+  qsincos(s.th1, &s1, &c1);
+  qsincos(s.th2, &s2, &c2);
+  const T az = T(Const::anchor_z);
+  const V3<T> d = mk<T>(-s2, s1 * c2, -c1 * c2);   // unit vector anchor -> load (F0 axes)
+  const V3<T> y2 = mk<T>(T(0), c1, s1);            // hinge-2 axis (F0 axes); hinge-1 axis is x
+  const V3<T> e_x = mk<T>(c2, s1 * s2, -c1 * s2);  // x axis of the tether frame F2 = Rx Ry (its z axis is -d)
+
+  // ---- fluid drag on link (frame F1 = Rx(th1)) and tether (frame F2), float32 ------------
+  V3<T> fD1, tD1, fD2, tD2;
+  {
+    const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
+    const V3<T> w2 = w1 + s.thd2 * y2;
+    const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);  // anchor velocity
+    const V3<T> vc2 = va + M.lc * cross(w2, d);                      // tether COM velocity
+    const T k1 = T(LinkFluid::klin), k2 = T(LinkFluid::kang), k3 = T(LinkFluid::ql), k4 = T(LinkFluid::qa);
+    // F0 -> F1 components: Rx^T v = (x, c1 y + s1 z, -s1 y + c1 z)
+    V3<T> fl, tl;
+    fluid(k1, k2, k3, k3, k3, k4, k4, k4, mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z),
+          mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z), &fl, &tl);
+    fD1 = mk<T>(fl.x, c1 * fl.y - s1 * fl.z, s1 * fl.y + c1 * fl.z);
+    tD1 = mk<T>(tl.x, c1 * tl.y - s1 * tl.z, s1 * tl.y + c1 * tl.z);
+    fluid(M.klin2, M.kang2, M.qlt2, M.qlt2, M.qla2, M.qat2, M.qat2, M.qaa2,
+          mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2)), mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2)), &fl, &tl);
+    fD2 = fl.x * e_x + fl.y * y2 - fl.z * d;
+    tD2 = tl.x * e_x + tl.y * y2 - tl.z * d;
+  }
+
+  // ---- velocity-product terms and generalised forces, HP ---------------------------------
+  const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc;
+  const HP c0z = M.c0z, azh = Const::anchor_z;
+  const HP dI = HP(M.I2a) - It;
+  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt), dh = cvt<HP>(d), y2h = cvt<HP>(y2);
+  const V3<HP> uh = mk<HP>(wh.x * wh.z, wh.y * wh.z, -(wh.x * wh.x + wh.y * wh.y));
+  const HP thd1 = s.thd1, thd2 = s.thd2;
+  const V3<HP> rho = lc * dh;                                         // anchor -> tether COM
+  const V3<HP> w1 = mk<HP>(wh.x + thd1, wh.y, wh.z);
+  const V3<HP> w2 = w1 + thd2 * y2h;
+  // accelerations with all generalised accelerations zero and origin acceleration g~
+  const V3<HP> aa = gth + azh * uh;                                   // anchor
+  const V3<HP> al1 = mk<HP>(HP(0), thd1 * wh.z, -thd1 * wh.y);        // thd1 * (w x xhat)
+  const V3<HP> al2 = al1 + thd2 * cross(w1, y2h);
+  const V3<HP> ac2 = aa + cross(al2, rho) + dot(w2, rho) * w2 - dot(w2, w2) * rho;
+  // inertial wrenches
+  const V3<HP> F0 = m0 * (gth + c0z * uh);
+  const V3<HP> N0 = mk<HP>(wh.y * wh.z * (HP(M.I0z) - HP(M.I0y)), wh.z * wh.x * (HP(M.I0x) - HP(M.I0z)),
+                           wh.x * wh.y * (HP(M.I0y) - HP(M.I0x)));
+  const V3<HP> F1 = m1 * aa;
+  const V3<HP> N1 = i1 * al1;
+  const V3<HP> F2 = m2 * ac2;
+  const V3<HP> N2 = It * al2 + (dI * dot(dh, al2)) * dh + (dI * dot(dh, w2)) * cross(w2, dh);
+  // applied minus inertial
+  const V3<HP> G0 = cvt<HP>(fD0) - F0, G1 = cvt<HP>(fD1) - F1, G2 = cvt<HP>(fD2) - F2;
+  const V3<HP> fl = cvt<HP>(fT) + G0 + G1 + G2;
+  const V3<HP> W2 = cvt<HP>(tD2) - N2 + cross(rho, G2);                // wrench on the tether about the anchor
+  const V3<HP> T1 = cvt<HP>(tD1) - N1;
+  const V3<HP> G12 = G1 + G2;
+  const V3<HP> fw = cvt<HP>(tT) + cvt<HP>(tD0) - N0 + mk<HP>(-c0z * G0.y, c0z * G0.x, HP(0)) + T1 +
+                    mk<HP>(-azh * G12.y, azh * G12.x, HP(0)) + W2;
+  const HP bd = Const::damping;
+  const HP ft1 = T1.x + W2.x - bd * thd1;
+  const HP ft2 = dot(y2h, W2) - bd * thd2;
+
+  // ---- mass matrix about the system COM: sums of non-negative terms ------------------------
+  const HP mt = m0 + m1 + m2, imt = frcp(mt);
+  const V3<HP> r2 = mk<HP>(rho.x, rho.y, rho.z + azh);
+  const V3<HP> S = mk<HP>(m2 * r2.x, m2 * r2.y, m0 * c0z + m1 * azh + m2 * r2.z);
+  const V3<HP> rc = imt * S;
+  const HP c1h = c1, s1h = s1, c2h = c2, s2h = s2;
+  const V3<HP> p1 = lc * mk<HP>(HP(0), c1h * c2h, s1h * c2h);          // xhat x rho
+  const V3<HP> p2 = lc * mk<HP>(-c2h, -s1h * s2h, c1h * s2h);          // y2 x rho
+  const V3<HP> q2 = r2 - rc;
+  const HP qx = -rc.x, qy = -rc.y, q0z = c0z - rc.z, q1z = azh - rc.z; // core and link COM offsets from the COM
+  const HP m01 = m0 + m1, base = i1 + It;
+  const HP zz01 = m0 * q0z * q0z + m1 * q1z * q1z, z01 = m0 * q0z + m1 * q1z;
+  const HP Jxx = HP(M.I0x) + base + dI * dh.x * dh.x + m01 * qy * qy + zz01 + m2 * (q2.y * q2.y + q2.z * q2.z);
+  const HP Jyy = HP(M.I0y) + base + dI * dh.y * dh.y + m01 * qx * qx + zz01 + m2 * (q2.x * q2.x + q2.z * q2.z);
+  const HP Jzz = HP(M.I0z) + base + dI * dh.z * dh.z + m01 * (qx * qx + qy * qy) + m2 * (q2.x * q2.x + q2.y * q2.y);
+  const HP Jxy = dI * dh.x * dh.y - m01 * qx * qy - m2 * q2.x * q2.y;
+  const HP Jxz = dI * dh.x * dh.z - qx * z01 - m2 * q2.x * q2.z;
+  const HP Jyz = dI * dh.y * dh.z - qy * z01 - m2 * q2.y * q2.z;
+  const V3<HP> B1 = mk<HP>(base, HP(0), HP(0)) + (dI * dh.x) * dh + m2 * cross(q2, p1);
+  const V3<HP> B2 = It * y2h + m2 * cross(q2, p2);
+  const HP mu = m2 * (mt - m2) * imt;
+  const HP lc2 = lc * lc;
+  const HP D1 = base + dI * s2h * s2h + mu * lc2 * c2h * c2h;
+  const HP D2 = It + mu * lc2;
+  const V3<HP> fwr = fw - cross(rc, fl);
+  const HP k = m2 * imt;
+  const HP g1 = ft1 - k * dot(p1, fl);
+  const HP g2 = ft2 - k * dot(p2, fl);
+
+  // ---- LDL^T of the 3x3 block, three right-hand sides ----------------------------------------
+  const HP d0 = frcp(Jxx);
+  const HP l10 = Jxy * d0, l20 = Jxz * d0;
+  const HP d1 = frcp(Jyy - l10 * Jxy);
+  const HP t21 = Jyz - l20 * Jxy;
+  const HP l21 = t21 * d1;
+  const HP d2 = frcp(Jzz - l20 * Jxz - l21 * t21);
+#define QD_SOLVE3(b, o)                                       \
+  {                                                           \
+    const HP y0 = (b).x, y1 = (b).y - l10 * y0;               \
+    const HP y2_ = (b).z - l20 * y0 - l21 * y1;               \
+    const HP z2 = y2_ * d2;                                   \
+    const HP z1 = y1 * d1 - l21 * z2;                         \
+    const HP z0 = y0 * d0 - l10 * z1 - l20 * z2;              \
+    (o) = mk<HP>(z0, z1, z2);                                 \
+  }
+  V3<HP> Xf, X1, X2;
+  QD_SOLVE3(fwr, Xf);
+  QD_SOLVE3(B1, X1);
+  QD_SOLVE3(B2, X2);
+#undef QD_SOLVE3
+  // 2x2 Schur complement on the hinges
+  const HP s11 = D1 - dot(B1, X1), s12 = -dot(B1, X2), s22 = D2 - dot(B2, X2);
+  const HP q1 = g1 - dot(B1, Xf), q2s = g2 - dot(B2, Xf);
+  const HP hb = HP(h) * bd;
+  V3<HP> a0ex;
+#define QD_FINISH(S11, S22, out, A0)                                                     \
+  {                                                                                      \
+    const HP idet = frcp((S11) * (S22) - s12 * s12);                                     \
+    const HP t1 = ((S22) * q1 - s12 * q2s) * idet, t2 = ((S11) * q2s - s12 * q1) * idet; \
+    const V3<HP> al = Xf - t1 * X1 - t2 * X2;                                            \
+    A0 = imt * (fl - cross(al, S) - (m2 * t1) * p1 - (m2 * t2) * p2);                    \
+    (out)->ang = cvt<T>(al); (out)->thdd1 = T(t1); (out)->thdd2 = T(t2);                 \
+  }
+  V3<HP> a0im;
+  QD_FINISH(s11, s22, ex, a0ex);
+  QD_FINISH(s11 + hb, s22 + hb, im, a0im);
+#undef QD_FINISH
   const V3<T> a0e = cvt<T>(a0ex);
-  *acc = accelerometer(a0e, ex->ang, at.gt, at.u);
-  ex->lin = mul(at.R, a0e);
-  im->lin = mul(at.R, cvt<T>(a0im));
+  *acc = a0e + gt + mk<T>(ex->ang.y * sz, -ex->ang.x * sz, T(0)) + sz * u;
+  ex->lin = mul(R, a0e);
+  im->lin = mul(R, cvt<T>(a0im));
 }
 
 // Euler advance of one substep with the accelerations `im`: activations, velocities, then positions with the NEW velocities

@@ -309,10 +309,12 @@ __device__ __forceinline__ void reset_bookkeeping(State<float>& s, uint32_t& epi
 }
 
 // reset of a truncated lane inside the step kernel: pool entry if it is there, inline sampling otherwise
-template <bool LOAD>
+// POOL = false: instantiations that are never launched with sampler workgroups (the 256-thread step kernels of large
+// batches) carry no pool code
+template <bool LOAD, bool POOL = true>
 __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e) {
   bool taken = false;
-  if (a.use_pool) {
+  if (POOL && a.use_pool) {
     float4* g = a.g;
     const int np = a.npad, base = pool_slot(e.episode);
     const float4 nx4 = g[(base + 4) * np + i];
@@ -441,7 +443,7 @@ __device__ unsigned long long qd_cstamps[64 * 3 * 12];
 #endif
 
 // ---- one full env step for the lane's env (everything after the state is in registers) ----
-template <bool LOAD, int SPEC>
+template <bool LOAD, int SPEC, bool POOL = true>
 __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, float4 action, float* obs_row, float* rew,
                                          uint8_t* trunc) {
   constexpr int NS = LOAD ? 33 : 29;
@@ -482,7 +484,7 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
     r = reward<float>(spec_reward<SPEC>(a), sv, act4, e.num_steps, e.ref, a.max_distance, &Rq);
   }
   if (a.auto_reset && tr) {
-    reset_in_step<LOAD>(a, i, e);
+    reset_in_step<LOAD, POOL>(a, i, e);
     if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, e.ref);
     if (term_kind != QD_TERM_SIMPLE) drone_state<float, LOAD>(e.s, e.acc, e.ref, e.par, sv, &Rq);
   }
@@ -501,7 +503,7 @@ template <bool LOAD, int BLOCK, int SPEC>
 __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 : 1)) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                 float* __restrict__ reward, uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
-  if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
+  if (BLOCK == 64 && (int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool"); 64-thread launches only
     sampler_wave<LOAD>(a, ((int)blockIdx.x - a.main_blocks) * BLOCK + threadIdx.x);
     return;
   }
@@ -523,7 +525,7 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
 #endif
     float r;
     uint8_t t;
-    env_step<LOAD, SPEC>(a, i, e, action, wtile + lane * a.D, &r, &t);
+    env_step<LOAD, SPEC, BLOCK == 64>(a, i, e, action, wtile + lane * a.D, &r, &t);
     QD_STAMP(4);
     store_env(a, i, e);
     __builtin_nontemporal_store(r, reward + i);
@@ -1388,10 +1390,6 @@ int qd_version(void) { return QD_VERSION; }
 // the tag makes the hash findable in the file without loading it (build.py: embedded_hash)
 static const char qd_source_hash_tagged[] = "QD_SOURCE_HASH=" QD_SOURCE_HASH;
 const char* qd_source_hash(void) { return qd_source_hash_tagged + sizeof("QD_SOURCE_HASH=") - 1; }
-int qd_host_wait_spin(int spin) {
-  QD_HIP(hipSetDeviceFlags(spin ? hipDeviceScheduleSpin : hipDeviceScheduleAuto));
-  return QD_OK;
-}
 #ifdef QD_STAMPS
 int qd_debug_read_stamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -4;
@@ -1664,7 +1662,7 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   do {                                                                                                            \
     KArgs kk = k;                                                                                                 \
     kk.main_blocks = (k.n + BLK - 1) / BLK;                                                                       \
-    QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3(kk.main_blocks * (k.use_pool ? 2 : 1)), dim3(BLK), 0, S(stream), kk, \
+    QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3(kk.main_blocks * ((k.use_pool && BLK == 64) ? 2 : 1)), dim3(BLK), 0, S(stream), kk, \
               actions, obs, reward, truncated);                                                                   \
   } while (0)
 #define QD_STEP_BLOCK(BLK)                                                   \

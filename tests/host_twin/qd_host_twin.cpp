@@ -212,3 +212,35 @@ void twin_tree_mass_matrix(const double* model16, const double* qpos, double* ou
   tree_mass_matrix(M, P, out64);
 }
 }
+
+// ---- forward(): the monolithic composition the step kernels use vs the pieces the cooperative kernel uses ----
+template <class T>
+static void fwd_pair(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out22) {
+  Model<T> M;
+  T* mp = reinterpret_cast<T*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = (T)model16[i];
+  State<T> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = qpos[7]; s.th2 = qpos[8];
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = qvel[6]; s.thd2 = qvel[7];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  for (int which = 0; which < 2; which++) {
+    Accel<T> ex, im;
+    V3<T> acc;
+    if (which == 0) forward<T, true>(M, s, (T)h, &ex, &im, &acc);
+    else forward_pieces<T>(M, s, (T)h, &ex, &im, &acc);
+    double* o = out22 + 19 * which;
+    o[0] = ex.lin.x; o[1] = ex.lin.y; o[2] = ex.lin.z; o[3] = ex.ang.x; o[4] = ex.ang.y; o[5] = ex.ang.z; o[6] = ex.thdd1; o[7] = ex.thdd2;
+    o[8] = im.lin.x; o[9] = im.lin.y; o[10] = im.lin.z; o[11] = im.ang.x; o[12] = im.ang.y; o[13] = im.ang.z; o[14] = im.thdd1; o[15] = im.thdd2;
+    o[16] = acc.x; o[17] = acc.y; o[18] = acc.z;
+  }
+}
+extern "C" {
+void twin_forward_pair_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out38) {
+  fwd_pair<double>(model16, qpos, qvel, act, h, out38);
+}
+void twin_forward_pair_f32(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out38) {
+  fwd_pair<float>(model16, qpos, qvel, act, h, out38);
+}
+}

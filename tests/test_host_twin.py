@@ -315,3 +315,31 @@ def test_three_assemblies_of_the_mass_matrix_agree(twin, orc):
         twin.twin_tree_mass_matrix(P(m16), P(qpos), P(got))
         want = orc.mass_matrix(m, qpos)
         np.testing.assert_allclose(got.reshape(8, 8), want, rtol=1e-9, atol=1e-11)
+
+
+def test_cooperative_pieces_equal_the_monolithic_forward(twin):
+    """qd_dynamics.h holds the load model's forward dynamics twice: forward(), which the single-lane kernels run, and the
+    pieces (applied / inertial wrench, mass factor, reduce, finish) k_step_coop runs in three wavefronts.  forward_pieces()
+    composes the pieces in one lane; here both are evaluated on the host for random states: the same accelerations and
+    accelerometer reading to 1e-11 in float64 (same algebra, different association), and in float32 to the rounding level the
+    GPU parity tests allow per step."""
+    rng = np.random.default_rng(77)
+    worst64, worst32 = 0.0, 0.0
+    for k in range(400):
+        raw = rand_raw(rng, 1)
+        m28 = np.zeros(28)
+        assert twin.twin_derive(P(raw), P(m28)) == 1
+        qpos = np.zeros(9); qpos[:3] = rng.uniform(-2, 2, 3) + [0, 0, 15]
+        q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q) * rng.uniform(0.9, 1.1)   # unnormalised on purpose
+        qpos[7:] = rng.normal(0, 0.6, 2)
+        qvel = np.concatenate([rng.normal(0, 3, 3), rng.normal(0, 4, 3), rng.normal(0, 3, 2)])
+        act = rng.uniform(-0.1, 1.2, 4)
+        o64, o32 = np.zeros(38), np.zeros(38)
+        twin.twin_forward_pair_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o64))
+        twin.twin_forward_pair_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o32))
+        scale = np.maximum(1.0, np.abs(o64[:19]))
+        worst64 = max(worst64, float(np.max(np.abs(o64[:19] - o64[19:]) / scale)))
+        worst32 = max(worst32, float(np.max(np.abs(o32[:19] - o32[19:]) / scale)))
+    print("pieces vs monolithic forward: float64 %.2e, float32 %.2e (relative to max(1, |value|))" % (worst64, worst32))
+    assert worst64 < 1e-11
+    assert worst32 < 5e-5
