@@ -365,7 +365,8 @@ def main():
     if not args.dry:
         ramp_s = float(os.environ.get("QD_BENCH_RAMP_S", "0"))
         t_r = time.perf_counter()
-        while state["total"] < 8192 or time.perf_counter() - t_r < ramp_s:
+        ramp_min = int(os.environ.get("QD_BENCH_RAMP_STEPS", "8192"))      # profiling runs shorten it to keep the traces small
+        while state["total"] < ramp_min or time.perf_counter() - t_r < ramp_s:
             run(T)
             if state["total"] % (8 * T) == 0:
                 sync()

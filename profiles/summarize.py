@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Condense rocprofv3 output directories (gpurun_out/...) into the small summaries kept under profiles/.
 
-usage: python profiles/summarize.py <round-tag> <stats_dir> [--pmc name=dir ...] [--calib dir]
+usage: python profiles/summarize.py <round-tag> <stats_dir> [--kernel substring] [--out dir] [--pmc name=dir ...] [--calib dir]
   stats_dir : output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python bench.py ...
   pmc dirs  : outputs of rocprofv3 --kernel-trace --pmc <counters> --output-format csv -d <dir> -- python bench.py ...
 """
@@ -50,20 +50,25 @@ def pmc(d, key="k_step"):
 
 def main():
     tag, stats_dir = sys.argv[1], sys.argv[2]
-    out = {"tag": tag, "kernel_stats": kernel_stats(stats_dir), "step_kernel_trace": trace_stats(stats_dir)}
+    key, outdir = "k_step", os.path.dirname(os.path.abspath(__file__))
+    for j, a in enumerate(sys.argv):
+        if a == "--kernel":
+            key = sys.argv[j + 1]
+        if a == "--out":
+            outdir = sys.argv[j + 1]
+    out = {"tag": tag, "kernel_filter": key, "kernel_stats": kernel_stats(stats_dir), "step_kernel_trace": trace_stats(stats_dir, key)}
     i = 3
     while i < len(sys.argv):
         if sys.argv[i] == "--pmc":
             name, d = sys.argv[i + 1].split("=")
-            out.setdefault("pmc", {})[name] = pmc(d)
+            out.setdefault("pmc", {})[name] = pmc(d, key)
             i += 2
         elif sys.argv[i] == "--calib":
             out["fetch_calibration"] = pmc(sys.argv[i + 1], key="")
             i += 2
         else:
             i += 1
-    here = os.path.dirname(os.path.abspath(__file__))
-    path = os.path.join(here, "%s_rocprof_summary.json" % tag)
+    path = os.path.join(outdir, "%s_rocprof_summary.json" % tag)
     json.dump(out, open(path, "w"), indent=1)
     print("wrote", path)
 
