@@ -202,7 +202,10 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
  * qd_pid_action  : one controller evaluation on the current state -> actions[N,4]; memory advances.
  * qd_rollout_pid : T closed-loop steps (controller -> vector_step) in ONE launch: obs[T,N,D],
  *                  reward[T,N], truncated[T,N], actions_out[T,N,4] (nullable).  Same results as
- *                  T x (qd_pid_action, qd_step).  QD_ERR_UNSUPPORTED for SimpleDrone configurations. */
+ *                  T x (qd_pid_action, qd_step).  QD_ERR_UNSUPPORTED for SimpleDrone configurations.
+ *                  Envs with floor_contact run the same loop launch by launch (the contact solve needs the
+ *                  register file a multi-step kernel would keep the state in) and require actions_out as
+ *                  the buffer between controller and step; qd_rollout steps such envs launch by launch too. */
 int qd_pid_reset(qd_env* env, const uint8_t* mask, void* stream);
 int qd_pid_action(qd_env* env, float* actions, void* stream);
 int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out,

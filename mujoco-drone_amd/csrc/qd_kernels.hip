@@ -427,15 +427,15 @@ __device__ unsigned long long qd_rstamps[64 * 2];
     __builtin_amdgcn_sched_barrier(0);                                                                \
     if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_stamps[blockIdx.x * 8 + (k)] = t_;           \
   } while (0)
-// cooperative step: 12 stamps per (workgroup, wave)
-__device__ unsigned long long qd_cstamps[64 * 3 * 12];
+// cooperative step: 16 stamps per (workgroup, wave)
+__device__ unsigned long long qd_cstamps[64 * 3 * 16];
 #define QD_CSTAMP(k)                                                                                        \
   do {                                                                                                      \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
     unsigned long long t_;                                                                                  \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                            \
     __builtin_amdgcn_sched_barrier(0);                                                                      \
-    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_cstamps[(blockIdx.x * 3 + role) * 12 + (k)] = t_;   \
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_cstamps[(blockIdx.x * 3 + role) * 16 + (k)] = t_;   \
   } while (0)
 #else
 #define QD_STAMP(k)
@@ -719,7 +719,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
       in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
     }
+    QD_CSTAMP(10);
     r = reduce_rhs(f, ap, in);
+    QD_CSTAMP(11);
     Accel<float> im;
     V3<double> a0im;
     finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
@@ -734,7 +736,9 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
                           mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
       e.acc = acc;
     }
+    QD_CSTAMP(12);
     integrate<float, true>(e.M, e.s, im, c0, c1, c2, c3, a.h);
+    QD_CSTAMP(13);
     e.flags &= ~FLAG_ACC_STALE;
     e.num_steps += 1;
     steps_post = e.num_steps;
@@ -744,6 +748,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       tr = !(qsqrt(dx * dx + dy * dy + dz * dz) <= a.max_distance) || e.num_steps >= a.max_steps;
     }
     coop_put_state(L, 0, lane, e.s, acc);
+    QD_CSTAMP(14);
     const bool rst = a.auto_reset && tr;
     bool taken = false;
     float4 nx4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -1409,7 +1414,7 @@ int qd_debug_read_pstamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd::qd_pstamps), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -4;
 }
 int qd_debug_read_cstamps(unsigned long long* out_host) {
-  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_cstamps), sizeof(unsigned long long) * 64 * 3 * 12) == hipSuccess ? 0 : -4;
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_cstamps), sizeof(unsigned long long) * 64 * 3 * 16) == hipSuccess ? 0 : -4;
 }
 int qd_debug_read_rstamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_rstamps), sizeof(unsigned long long) * 64 * 2) == hipSuccess ? 0 : -4;
@@ -1764,18 +1769,27 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   if (T < 0) return fail(QD_ERR_INVALID, "negative step count");
   if (T == 0) return QD_OK;
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
+  if (env->spec == SPEC_FLOOR) {
+    // floor contact: the contact solve wants the whole register file for itself; with the env state kept in registers across
+    // steps on top of it the multi-step kernel spilled 135 registers, so these envs are stepped launch by launch (same results)
+    const size_t D = (size_t)env->D;
+    for (int t = 0; t < T; t++) {
+      const int rc = qd_step(env, actions + (size_t)t * k.n * 4, (int64_t)k.n * 4, obs + (size_t)t * k.n * D, reward + (size_t)t * k.n,
+                             truncated + (size_t)t * k.n, stream);
+      if (rc != QD_OK) return rc;
+    }
+    return QD_OK;
+  }
   const dim3 grid(blocks64(k.n)), block(64);
 #define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout<LOADV, 64, SPECV>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated)
   if (env->load) {
     if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
     else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
-    else if (env->spec == SPEC_FLOOR) QD_ROLL(true, SPEC_FLOOR);
     else QD_ROLL(true, SPEC_GENERIC);
   } else {
     if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
-    else if (env->spec == SPEC_FLOOR) QD_ROLL(false, SPEC_FLOOR);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL
@@ -1808,17 +1822,28 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
   if (T == 0) return QD_OK;
   if (!obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   if (env->ka.term_kind == QD_TERM_SIMPLE) return fail(QD_ERR_UNSUPPORTED, "the PID cascade drives BaseDroneEnv models (attitude_test.py), not SimpleDrone");
+  if (env->spec == SPEC_FLOOR) {
+    // floor contact: launch by launch (see qd_rollout) -- controller, step, and fresh controllers for the envs that were re-sampled
+    if (!actions_out) return fail(QD_ERR_INVALID, "a floor-contact PID rollout runs launch by launch and needs actions_out [T,N,4] as its action buffer");
+    const size_t D = (size_t)env->D;
+    for (int t = 0; t < T; t++) {
+      float* a_t = actions_out + (size_t)t * k.n * 4;
+      int rc = qd_pid_action(env, a_t, stream);
+      if (rc == QD_OK) rc = qd_step(env, a_t, (int64_t)k.n * 4, obs + (size_t)t * k.n * D, reward + (size_t)t * k.n, truncated + (size_t)t * k.n, stream);
+      if (rc == QD_OK && k.auto_reset) rc = qd_pid_reset(env, truncated + (size_t)t * k.n, stream);
+      if (rc != QD_OK) return rc;
+    }
+    return QD_OK;
+  }
   const dim3 grid(blocks64(k.n)), block(64);
 #define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout_pid<LOADV, SPECV>), grid, block, 0, S(stream), k, T, obs, reward, truncated, actions_out)
   if (env->load) {
     if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
     else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
     else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
-    else if (env->spec == SPEC_FLOOR) QD_ROLL(true, SPEC_FLOOR);
     else QD_ROLL(true, SPEC_GENERIC);
   } else {
     if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
-    else if (env->spec == SPEC_FLOOR) QD_ROLL(false, SPEC_FLOOR);
     else QD_ROLL(false, SPEC_GENERIC);
   }
 #undef QD_ROLL

@@ -186,9 +186,11 @@ class DeviceEnv:
         obs = torch.empty((T, self.n, self.D), dtype=torch.float32, **kw)
         reward = torch.empty((T, self.n), dtype=torch.float32, **kw)
         truncated = torch.empty((T, self.n), dtype=torch.uint8, **kw)
-        actions = torch.empty((T, self.n, 4), dtype=torch.float32, **kw) if want_actions else None
+        # floor-contact envs run the loop launch by launch and use the action buffer between controller and step
+        need_actions = want_actions or bool(self.cfg.floor_contact)
+        actions = torch.empty((T, self.n, 4), dtype=torch.float32, **kw) if need_actions else None
         L.check(self.lib.qd_rollout_pid(self.handle, T, _ptr(obs), _ptr(reward), _ptr(truncated),
-                                        _ptr(actions) if want_actions else None, self._stream()))
+                                        _ptr(actions) if need_actions else None, self._stream()))
         return (obs, reward, truncated, actions) if want_actions else (obs, reward, truncated)
 
     def observe(self, out=None):

@@ -19,22 +19,24 @@ for i in range(300):
     env._dev.step(a[i % 8])
 torch.cuda.synchronize()
 lib = env._dev.lib
-buf = (C.c_ulonglong * (64 * 3 * 12))()
+buf = (C.c_ulonglong * (64 * 3 * 16))()
 acc = []
 for rep in range(50):
     for i in range(20):
         env._dev.step(a[i % 8])
     torch.cuda.synchronize()
     assert lib.qd_debug_read_cstamps(buf) == 0
-    st = np.array(buf[:], dtype=np.int64).reshape(64, 3, 12)[:, :, :10]
+    st = np.array(buf[:], dtype=np.int64).reshape(64, 3, 16)[:, :, :15]
     acc.append(st - st[:, :, :1].min(axis=1, keepdims=True))      # relative to the workgroup's first wave start
-acc = np.array(acc).reshape(-1, 3, 10)
+acc = np.array(acc).reshape(-1, 3, 15)
 med = np.median(acc, axis=0)
 names = ["start", "loads arrived", "phase 1 done", "barrier 1 passed", "phase 2 done", "barrier 2 passed", "phase 3 done",
-         "barrier 3 passed", "flush issued", "stores drained"]
+         "barrier 3 passed", "flush issued", "stores drained", "A: hand-over read", "A: rhs reduced", "A: accel solved", "A: integrated",
+         "A: state published"]
 print("median cycles since the workgroup's first wave started (waves A / B / C):")
 for k, nm in enumerate(names):
     print("  %-18s %7.0f %7.0f %7.0f" % (nm, med[0, k], med[1, k], med[2, k]))
 one = acc[-64:]
 tot = one[:, :, 9].max(axis=1)
+print('wave A inside phase 2 (median):', ' '.join('%s %d' % (n, med[0, 10 + k]) for k, n in enumerate(['read', 'rhs', 'solved', 'integrated', 'published'])))
 print("slowest workgroup of the last launch:", one[np.argmax(tot)].astype(int).tolist())
