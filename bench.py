@@ -472,6 +472,17 @@ def main():
                 traffic = json.load(open(pmc)).get(args.config, {}).get(str(n))
             except Exception:
                 traffic = None
+        # the committed rocprofv3 kernel trace of this command (profiles/, tools/profile_r02.sh trace): the same kernel's average
+        # duration under the profiler, for the reader who wants to set the live figure beside it.  The profiler's per-dispatch
+        # instrumentation adds ~0.5-0.8 us to a 4 us kernel (the live HIP-event period measured INSIDE the profiled run reads
+        # 6.8-7.5 us against 4.2 un-profiled), so the two bracket the kernel rather than coincide.
+        prof_us = None
+        prof = os.path.join(ROOT, "profiles", "r02_default_n4096_rocprof_summary.json")
+        if os.path.exists(prof) and args.config == "config3" and n == 4096:
+            try:
+                prof_us = json.load(open(prof))["step_kernel_trace"]["avg_ns"] * 1e-3
+            except Exception:
+                prof_us = None
         copy_gbps = measured_copy_gbps(device)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
@@ -479,12 +490,15 @@ def main():
                            "kernel_us_source": "HIP events on the launch stream around %d back-to-back k_step launches (graph-replayed "
                                                "1024-step fragments), independent of --steps" % klaunches,
                            "timed_region_us_per_step": kus_timed, "isolated_launch_us": iso_us,
+                           "rocprofv3_avg_kernel_us": prof_us,
+                           "frac_at_rocprofv3_duration": (bytes_per_launch / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof_us else None,
                            "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
                            "env_steps_per_launch": n, "measured_copy_GBps": copy_gbps,
                            "frac_of_measured_copy": achieved / copy_gbps, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                           "WRITE_SIZE passes of this command, FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
-                           "note": "4096 envs = 64 wavefronts on 1024 SIMDs: the launch is latency/occupancy-bound, "
-                                   "not HBM-bound (see DESIGN.md and the env-count sweep in `extras`)"}
+                           "WRITE_SIZE passes of this command with direct launches, tools/profile_r02.sh; FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
+                           "note": "4096 envs = 192 wavefronts (3 per 64 envs, k_step_coop) on 1024 SIMDs: the launch is a dependent "
+                                   "instruction chain between two kernel boundaries, not HBM-bound (see DESIGN.md and the env-count "
+                                   "sweep in `extras`: 54-57 % of the roofline from 10^6 envs)"}
         if not args.no_extras and world == 1:
             extras = {}
             try:

@@ -339,6 +339,49 @@ QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
   return a0e + gt + mk<T>(ang_ex.y * sz, -ang_ex.x * sz, T(0)) + sz * u;
 }
 
+// The accelerometer reading as an affine function of the activations at a fixed state: reading(a) = c0 + sum_i a_i col_i.
+// Thrust and yaw reaction are linear in the activations and nothing else in the forward dynamics depends on them, so one
+// factorisation serves the five right-hand sides.  Used by the reset pool (qd_kernels.hip): an env's activations survive a
+// reset (reference quirk C-2) and are only known when it happens, but c0 and the four columns can be prepared with the
+// pre-sampled state, which turns mj_forward's sensor refresh at reset time into 12 multiply-adds.
+template <class T>
+QD_HD void sensor_affine(const Model<T>& M, State<T> s, T h, V3<T>* c0, V3<T> col[4]) {
+  using HP = typename HighPrec<T>::type;
+  s.a0 = s.a1 = s.a2 = s.a3 = T(0);
+  const Att<T> at = attitude(s);
+  const Tether<T> tg = tether_geometry(s.th1, s.th2);
+  const Applied<T> ap = applied_wrench(M, s, at, tg);
+  const Inertial<HP> in = inertial_wrench(M, s, at.gt, at.w, tg);
+  const Factor<HP> f = mass_factor<true>(M, tg, h);
+  const T sz = T(Const::sense_z);
+  {
+    const Rhs<HP> r = reduce_rhs<true>(f, ap, in);
+    V3<HP> a0;
+    V3<T> ang;
+    T d1, d2;
+    finish_accel<false, true>(f, r, &a0, &ang, &d1, &d2);
+    *c0 = accelerometer(cvt<T>(a0), ang, at.gt, at.u);
+  }
+  Inertial<HP> zero;
+  zero.F = mk<HP>(HP(0), HP(0), HP(0)); zero.Tq = zero.F; zero.t1 = zero.t2 = HP(0);
+  // unit activation of rotor i: thrust gearF along z at (+-rot, +-rot, 0), yaw reaction +-gearT (applied_wrench)
+  const T sx[4] = {T(-1), T(1), T(1), T(-1)}, sy[4] = {T(-1), T(-1), T(1), T(1)}, sg[4] = {T(1), T(-1), T(1), T(-1)};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    Applied<T> d;
+    d.F = mk<T>(T(0), T(0), M.gearF);
+    d.Tq = mk<T>(M.rot * M.gearF * sx[i], M.rot * M.gearF * sy[i], M.gearT * sg[i]);
+    d.t1 = d.t2 = T(0);
+    const Rhs<HP> r = reduce_rhs<true>(f, d, zero);
+    V3<HP> a0;
+    V3<T> ang;
+    T d1, d2;
+    finish_accel<false, true>(f, r, &a0, &ang, &d1, &d2);
+    const V3<T> a0e = cvt<T>(a0);
+    col[i] = mk<T>(a0e.x + ang.y * sz, a0e.y - ang.x * sz, a0e.z);
+  }
+}
+
 // The same forward dynamics as forward() below, composed from the pieces above in one lane (load model).  The step
 // kernels do NOT use it: hipcc schedules the monolithic forward() with fewer live values (36 vs 52 bytes of scratch in the
 // 256-thread instantiation, 12-16 % of the step time in the HBM-bound regime), so forward() stays as it was and the pieces

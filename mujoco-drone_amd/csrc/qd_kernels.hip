@@ -43,6 +43,8 @@ enum Group {
   G_POS = 0, G_QUAT, G_VEL, G_ANG, G_ACT, G_AUX, G_ACC, G_M0, G_M1, G_M2, G_M3, G_M4, G_M5, G_M6, G_P0, G_P1, G_REF,
   G_NX0, G_NX1, G_NX2, G_NX3, G_NX4,  // reset pool, slot 0: pre-sampled initial state of the env's episodes with an EVEN counter
   G_NY0, G_NY1, G_NY2, G_NY3, G_NY4,  //             slot 1: ... with an ODD counter (filled by sampler waves, see "reset pool")
+  G_NXA0, G_NXA1, G_NXA2, G_NXA3,     // slot 0: the new episode's first accelerometer reading as c0 + sum a_i col_i (15 floats), for
+  G_NYA0, G_NYA1, G_NYA2, G_NYA3,     // slot 1: configurations whose observation row carries the sensor (obs_needs_acc)
   G_C0, G_C1, G_C2, G_C3,             // memory of the analytic PID cascade (qd_pid.h); touched only by the qd_pid_* entry points
   NUM_GROUPS
 };
@@ -254,6 +256,19 @@ __device__ __forceinline__ void sample_episode(const KArgs& a, int i, uint32_t e
 // no fence, and its planes may be fetched in any order and ahead of time (k_step_coop).  A lost race costs speed only:
 // a request counted twice re-checks 64 tags, an entry that is not there is sampled inline.
 __device__ __forceinline__ int pool_slot(uint32_t episode) { return (episode & 1u) ? (int)G_NY0 : (int)G_NX0; }
+__device__ __forceinline__ int pool_acc_slot(uint32_t episode) { return (episode & 1u) ? (int)G_NYA0 : (int)G_NXA0; }
+// entry stages (word z of the tag plane): 0 empty / consumed, 1 state sampled, 2 state + the accelerometer's affine form
+constexpr uint32_t POOL_STATE = 1u, POOL_FULL = 2u;
+
+// the 15 floats of (c0, col[0..3]) in four planes, and the reading they give for activations a
+struct SensorAffine { float4 p[4]; };
+__device__ __forceinline__ V3<float> sensor_from_affine(const SensorAffine& sa, float a0, float a1, float a2, float a3) {
+  const float4 p0 = sa.p[0], p1 = sa.p[1], p2 = sa.p[2], p3 = sa.p[3];
+  // planes: (c0.xyz, col0.x) (col0.yz, col1.xy) (col1.z, col2.xyz) (col3.xyz, -)
+  return mk<float>(p0.x + a0 * p0.w + a1 * p1.z + a2 * p2.y + a3 * p3.x,
+                   p0.y + a0 * p1.x + a1 * p1.w + a2 * p2.z + a3 * p3.y,
+                   p0.z + a0 * p1.y + a1 * p2.x + a2 * p2.w + a3 * p3.z);
+}
 
 __device__ __forceinline__ void pool_store(const KArgs& a, int i, uint32_t episode, const State<float>& s) {
   float4* g = a.g;
@@ -262,17 +277,46 @@ __device__ __forceinline__ void pool_store(const KArgs& a, int i, uint32_t episo
   g[(base + 1) * np + i] = make_float4(s.qw, s.qx, s.qy, s.qz);
   g[(base + 2) * np + i] = make_float4(s.vx, s.vy, s.vz, s.th2);
   g[(base + 3) * np + i] = make_float4(s.wx, s.wy, s.wz, s.thd1);
-  g[(base + 4) * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(1u), 0.f);
+  g[(base + 4) * np + i] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(POOL_STATE), 0.f);
 }
 
-// make the slot of episode `next` hold its sample (no-op if it already does)
+// Bring the slot of episode `next` one stage closer to complete; returns true once it is.  Stage 1 draws the state (~1000
+// instructions); stage 2 -- only for configurations whose observation row carries the accelerometer -- evaluates the sensor's
+// affine form at that state (~1300).  One stage per call: an entry is prepared an episode ahead, so there is no hurry, and a
+// sampler wave that did both in one launch would outlast the physics waves it is meant to hide behind.
 template <bool LOAD>
-__device__ __forceinline__ void pool_fill(const KArgs& a, int i, uint32_t next) {
-  const float4 nx4 = a.g[(pool_slot(next) + 4) * a.npad + i];
-  if (__float_as_uint(nx4.z) != 0u && __float_as_uint(nx4.y) == next) return;
-  State<float> s;
-  sample_episode<LOAD>(a, i, next, s);
-  pool_store(a, i, next, s);
+__device__ __forceinline__ bool pool_fill(const KArgs& a, int i, uint32_t next) {
+  float4* g = a.g;
+  const int np = a.npad, base = pool_slot(next);
+  const float4 nx4 = g[(base + 4) * np + i];
+  const uint32_t stage = __float_as_uint(nx4.y) == next ? __float_as_uint(nx4.z) : 0u;
+  const uint32_t want = (LOAD && a.obs_needs_acc) ? POOL_FULL : POOL_STATE;
+  if (stage >= want) return true;
+  if (stage == 0u) {
+    State<float> s;
+    sample_episode<LOAD>(a, i, next, s);
+    pool_store(a, i, next, s);
+    return want == POOL_STATE;
+  }
+  if constexpr (LOAD) {
+    EnvRegs e;
+    load_env<true, false, false>(a, i, e);   // for the model; the state is the pre-sampled one
+    const float4 p = g[(base + 0) * np + i], q = g[(base + 1) * np + i], v = g[(base + 2) * np + i], w = g[(base + 3) * np + i];
+    e.s.px = p.x; e.s.py = p.y; e.s.pz = p.z; e.s.th1 = p.w;
+    e.s.qw = q.x; e.s.qx = q.y; e.s.qy = q.z; e.s.qz = q.w;
+    e.s.vx = v.x; e.s.vy = v.y; e.s.vz = v.z; e.s.th2 = v.w;
+    e.s.wx = w.x; e.s.wy = w.y; e.s.wz = w.z; e.s.thd1 = w.w;
+    e.s.thd2 = nx4.x;
+    V3<float> c0, col[4];
+    sensor_affine<float>(e.M, e.s, a.h, &c0, col);
+    const int ab = pool_acc_slot(next);
+    g[(ab + 0) * np + i] = make_float4(c0.x, c0.y, c0.z, col[0].x);
+    g[(ab + 1) * np + i] = make_float4(col[0].y, col[0].z, col[1].x, col[1].y);
+    g[(ab + 2) * np + i] = make_float4(col[1].z, col[2].x, col[2].y, col[2].z);
+    g[(ab + 3) * np + i] = make_float4(col[3].x, col[3].y, col[3].z, 0.f);
+    g[(base + 4) * np + i] = make_float4(nx4.x, nx4.y, __uint_as_float(POOL_FULL), 0.f);
+  }
+  return true;
 }
 
 // sample_state for this lane's env, episode counter advanced.  eager_sensor: run mj_forward's sensor
@@ -283,7 +327,8 @@ __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e, bool
   sample_episode<LOAD>(a, i, e.episode, e.s);
   e.episode += 1u;
   e.num_steps = 0;
-  if (a.use_pool) pool_fill<LOAD>(a, i, e.episode);   // the new counter's own entry: samplers only ever fill the one after it
+  // the new counter's own entry (samplers only ever fill the one after it); both stages: a reset kernel is not in a hurry
+  if (a.use_pool && !pool_fill<LOAD>(a, i, e.episode)) pool_fill<LOAD>(a, i, e.episode);
   if (eager_sensor) refresh_sensor<LOAD>(a, e);
   else e.flags |= FLAG_ACC_STALE;
 }
@@ -295,8 +340,10 @@ __device__ __forceinline__ void sampler_wave(const KArgs& a, int j) {
   if ((w << 6) >= a.n) return;
   const uint32_t pending = __hip_atomic_load(a.need + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (pending == 0u) return;
-  if (j < a.n) pool_fill<LOAD>(a, j, __float_as_uint(a.g[G_AUX * a.npad + j].z) + 1u);
-  if ((threadIdx.x & 63) == 0) __hip_atomic_fetch_sub(a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  bool done = true;
+  if (j < a.n) done = pool_fill<LOAD>(a, j, __float_as_uint(a.g[G_AUX * a.npad + j].z) + 1u);
+  // entries that still lack a stage keep the request alive: the next launch's sampler comes back for them
+  if (__all(done ? 1 : 0) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_sub(a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // what a reset does to everything but the sampled state (shared by the single-wave and the cooperative step)
@@ -313,7 +360,8 @@ __device__ __forceinline__ void reset_bookkeeping(State<float>& s, uint32_t& epi
 // batches) carry no pool code
 template <bool LOAD, bool POOL = true>
 __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e) {
-  bool taken = false;
+  bool taken = false, have_sa = false;
+  SensorAffine sa;
   if (POOL && a.use_pool) {
     float4* g = a.g;
     const int np = a.npad, base = pool_slot(e.episode);
@@ -325,6 +373,12 @@ __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e)
       e.s.vx = v.x; e.s.vy = v.y; e.s.vz = v.z; e.s.th2 = v.w;
       e.s.wx = w.x; e.s.wy = w.y; e.s.wz = w.z; e.s.thd1 = w.w;
       e.s.thd2 = nx4.x;
+      if (LOAD && a.obs_needs_acc && __float_as_uint(nx4.z) == POOL_FULL) {
+        const int ab = pool_acc_slot(e.episode);
+#pragma unroll
+        for (int k = 0; k < 4; k++) sa.p[k] = g[(ab + k) * np + i];
+        have_sa = true;
+      }
       g[(base + 4) * np + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
       taken = true;
     }
@@ -332,8 +386,14 @@ __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e)
   }
   if (!taken) sample_episode<LOAD>(a, i, e.episode, e.s);
   reset_bookkeeping(e.s, e.episode, e.num_steps);
-  if (a.obs_needs_acc) refresh_sensor<LOAD>(a, e);
-  else e.flags |= FLAG_ACC_STALE;
+  if (a.obs_needs_acc) {
+    // the new episode's first row reads the sensor at the new state (set_state -> mj_forward): from the pool's affine form if the
+    // entry carried it, else by running the forward dynamics again
+    if (have_sa) { e.acc = sensor_from_affine(sa, e.s.a0, e.s.a1, e.s.a2, e.s.a3); e.flags &= ~FLAG_ACC_STALE; }
+    else refresh_sensor<LOAD>(a, e);
+  } else {
+    e.flags |= FLAG_ACC_STALE;
+  }
 }
 
 // ---- observation rows ---------------------------------------------------------------
@@ -624,10 +684,12 @@ __device__ __forceinline__ void coop_obs_part(const KArgs& a, int i, int lane, c
 template <int SPEC>
 __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
-  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM, "cooperative step: the load model's training configurations");
+  // train_PPO.py / train_RMA.py's configuration only.  train_LSTM.py's (SPEC_LSTM: the row carries the accelerometer, the reward
+  // is the 150-instruction pendulum-energy one) was built too and lost to the single-wave kernel once the reset pool delivered
+  // the sensor's affine form (6.46 against 5.41 us per step at 8192 envs): its extra work all lands on wave A's serial phases.
+  static_assert(SPEC == SPEC_RMA, "cooperative step: LocalFrameRPYParamsEnv + distance_energy_reward on the load model");
   constexpr int D = spec_obs_dim<SPEC>();
   constexpr int KIND = SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : (int)OBS_FULLSTATE;
-  constexpr bool OBS_ACC = SPEC == SPEC_LSTM;   // the observation row carries the accelerometer reading
   __shared__ CoopLds L;
   if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
     sampler_wave<true>(a, ((int)blockIdx.x - a.main_blocks) * COOP_THREADS + threadIdx.x);
@@ -719,26 +781,13 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
       in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
     }
-    QD_CSTAMP(10);
     r = reduce_rhs(f, ap, in);
-    QD_CSTAMP(11);
     Accel<float> im;
     V3<double> a0im;
     finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
     im.lin = mul(R, cvt<float>(a0im));
     w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
-    if (OBS_ACC) {  // the row needs this step's reading: damping-explicit accelerations before the hand-over
-      Accel<float> ex;
-      V3<double> a0ex;
-      finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
-      const float g = float(Const::gravity);
-      acc = accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
-                          mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
-      e.acc = acc;
-    }
-    QD_CSTAMP(12);
     integrate<float, true>(e.M, e.s, im, c0, c1, c2, c3, a.h);
-    QD_CSTAMP(13);
     e.flags &= ~FLAG_ACC_STALE;
     e.num_steps += 1;
     steps_post = e.num_steps;
@@ -748,7 +797,6 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       tr = !(qsqrt(dx * dx + dy * dy + dz * dz) <= a.max_distance) || e.num_steps >= a.max_steps;
     }
     coop_put_state(L, 0, lane, e.s, acc);
-    QD_CSTAMP(14);
     const bool rst = a.auto_reset && tr;
     bool taken = false;
     float4 nx4 = make_float4(0.f, 0.f, 0.f, 0.f);
@@ -772,8 +820,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       e.s = ns;
       const uint32_t consumed = e.episode;
       reset_bookkeeping(e.s, e.episode, e.num_steps);
-      if (OBS_ACC) refresh_sensor<true>(a, e);   // the new episode's first row reads the sensor at the new state
-      else e.flags |= FLAG_ACC_STALE;
+      e.flags |= FLAG_ACC_STALE;   // the row does not carry the sensor: recomputed by the next step, or by a getter that runs first
       coop_put_state(L, 1, lane, e.s, e.acc);
       // global side effects last: nothing in this phase waits behind them (memory operations retire in order)
       if (a.use_pool) {
@@ -790,7 +837,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
   if (live) {
     if (role == 0) {
       store_env_state(a, i, e);   // positions / velocities / activations / counters: on their way while the rest is computed
-      if (!OBS_ACC) {
+      {
         Accel<float> ex;
         V3<double> a0ex;
         finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
@@ -1696,13 +1743,12 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
       else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
     }                                                                        \
   } while (0)
-  if (env->load && (env->spec == SPEC_RMA || env->spec == SPEC_LSTM) && k.n <= qd_coop_max_envs()) {
-    // small batches of the training configurations: three wavefronts per 64 envs (k_step_coop)
+  if (env->load && env->spec == SPEC_RMA && k.n <= qd_coop_max_envs()) {
+    // small batches of train_PPO.py / train_RMA.py's configuration: three wavefronts per 64 envs (k_step_coop)
     KArgs kk = k;
     kk.main_blocks = blocks64(k.n);
     const dim3 grid(kk.main_blocks + (k.use_pool ? (k.n + COOP_THREADS - 1) / COOP_THREADS : 0));
-    if (env->spec == SPEC_RMA) QD_LAUNCH((k_step_coop<SPEC_RMA>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
-    else QD_LAUNCH((k_step_coop<SPEC_LSTM>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
+    QD_LAUNCH((k_step_coop<SPEC_RMA>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
   } else if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(256);
   else QD_STEP_BLOCK(64);
 #undef QD_STEP_BLOCK

@@ -22,7 +22,8 @@ except AttributeError:  # pragma: no cover
 
 # float4 planes of the arena, in the order of `enum Group` in csrc/qd_kernels.hip (tests/test_host_logic.py keeps the two in step)
 ARENA_PLANES = ["POS", "QUAT", "VEL", "ANG", "ACT", "AUX", "ACC", "M0", "M1", "M2", "M3", "M4", "M5", "M6", "P0", "P1", "REF",
-                "NX0", "NX1", "NX2", "NX3", "NX4", "NY0", "NY1", "NY2", "NY3", "NY4", "C0", "C1", "C2", "C3"]
+                "NX0", "NX1", "NX2", "NX3", "NX4", "NY0", "NY1", "NY2", "NY3", "NY4", "NXA0", "NXA1", "NXA2", "NXA3",
+                "NYA0", "NYA1", "NYA2", "NYA3", "C0", "C1", "C2", "C3"]
 
 
 class DeviceEnv:

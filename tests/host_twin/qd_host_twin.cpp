@@ -244,3 +244,27 @@ void twin_forward_pair_f32(const double* model16, const double* qpos, const doub
   fwd_pair<float>(model16, qpos, qvel, act, h, out38);
 }
 }
+
+// ---- accelerometer as an affine function of the activations (reset pool) vs forward() at those activations ----
+extern "C" {
+void twin_sensor_affine_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out6) {
+  Model<double> M;
+  double* mp = reinterpret_cast<double*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = model16[i];
+  State<double> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = qpos[7]; s.th2 = qpos[8];
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = qvel[6]; s.thd2 = qvel[7];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  V3<double> c0, col[4];
+  sensor_affine<double>(M, s, h, &c0, col);
+  out6[0] = c0.x + act[0] * col[0].x + act[1] * col[1].x + act[2] * col[2].x + act[3] * col[3].x;
+  out6[1] = c0.y + act[0] * col[0].y + act[1] * col[1].y + act[2] * col[2].y + act[3] * col[3].y;
+  out6[2] = c0.z + act[0] * col[0].z + act[1] * col[1].z + act[2] * col[2].z + act[3] * col[3].z;
+  Accel<double> ex, im;
+  V3<double> acc;
+  forward<double, true>(M, s, h, &ex, &im, &acc);
+  out6[3] = acc.x; out6[4] = acc.y; out6[5] = acc.z;
+}
+}

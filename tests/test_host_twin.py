@@ -343,3 +343,24 @@ def test_cooperative_pieces_equal_the_monolithic_forward(twin):
     print("pieces vs monolithic forward: float64 %.2e, float32 %.2e (relative to max(1, |value|))" % (worst64, worst32))
     assert worst64 < 1e-11
     assert worst32 < 5e-5
+
+
+def test_sensor_is_affine_in_the_activations(twin):
+    """sensor_affine (qd_dynamics.h): c0 + sum a_i col_i equals the accelerometer of forward() at the same state and
+    activations -- what lets the reset pool prepare a new episode's first sensor reading before the activations are known"""
+    rng = np.random.default_rng(78)
+    worst = 0.0
+    for k in range(300):
+        raw = rand_raw(rng, 1)
+        m28 = np.zeros(28)
+        assert twin.twin_derive(P(raw), P(m28)) == 1
+        qpos = np.zeros(9); qpos[:3] = rng.uniform(-2, 2, 3) + [0, 0, 15]
+        q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q)
+        qpos[7:] = rng.normal(0, 0.6, 2)
+        qvel = np.concatenate([rng.normal(0, 3, 3), rng.normal(0, 4, 3), rng.normal(0, 3, 2)])
+        act = rng.uniform(-0.2, 1.3, 4)
+        o = np.zeros(6)
+        twin.twin_sensor_affine_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o))
+        worst = max(worst, float(np.max(np.abs(o[:3] - o[3:]) / np.maximum(1.0, np.abs(o[3:])))))
+    print("affine sensor vs forward(): %.2e" % worst)
+    assert worst < 1e-11
