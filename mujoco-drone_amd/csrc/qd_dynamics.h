@@ -241,6 +241,7 @@ struct Factor {
   // folded here so that the solve (the serial part of the step: everything waits for it) is as short as possible
   V3<HP> Sm, kp1, kp2;            // imt * S, (m2 imt) * p1, (m2 imt) * p2
   HP idet_ex, idet_im, hb;        // 1 / det of the Schur complement without / with the implicit damping hb on its diagonal
+  HP ixx, ixy, ixz, iyy, iyz, izz;  // J^-1 written out: a right-hand side then costs a 3-deep product instead of a 9-deep substitution
 };
 // PRE: also fold the products and reciprocals the solve needs (cooperative kernel: the factorisation has slack, the solve
 // does not); without it they are formed where they are used, which keeps fewer values alive (single-lane composition)
@@ -293,6 +294,9 @@ QD_HD Factor<typename HighPrec<T>::type> mass_factor(const Model<T>& M, const Te
     f.Sm = imt * S; f.kp1 = k * p1; f.kp2 = k * p2;
     f.idet_ex = frcp(f.s11 * f.s22 - f.s12 * f.s12);
     f.idet_im = frcp((f.s11 + f.hb) * (f.s22 + f.hb) - f.s12 * f.s12);
+    // J^-1 = L^-T D^-1 L^-1 column by column (unit vectors through the factor)
+    const V3<HP> cx = ldl_solve(f, mk<HP>(HP(1), HP(0), HP(0))), cy = ldl_solve(f, mk<HP>(HP(0), HP(1), HP(0)));
+    f.ixx = cx.x; f.ixy = cx.y; f.ixz = cx.z; f.iyy = cy.y; f.iyz = cy.z; f.izz = f.d2;
   }
   return f;
 }
@@ -313,7 +317,9 @@ QD_HD Rhs<HP> reduce_rhs(const Factor<HP>& f, const Applied<T>& ap, const Inerti
   const HP k = f.m2 * f.imt;
   const HP g1 = PRE ? ft1 - dot(f.kp1, r.fl) : ft1 - k * dot(f.p1, r.fl);
   const HP g2 = PRE ? ft2 - dot(f.kp2, r.fl) : ft2 - k * dot(f.p2, r.fl);
-  r.Xf = ldl_solve(f, fwr);
+  if (PRE) r.Xf = mk<HP>(f.ixx * fwr.x + f.ixy * fwr.y + f.ixz * fwr.z, f.ixy * fwr.x + f.iyy * fwr.y + f.iyz * fwr.z,
+                         f.ixz * fwr.x + f.iyz * fwr.y + f.izz * fwr.z);
+  else r.Xf = ldl_solve(f, fwr);
   r.q1 = g1 - dot(f.B1, r.Xf);
   r.q2 = g2 - dot(f.B2, r.Xf);
   return r;
@@ -585,12 +591,16 @@ QD_HD void forward(const Model<T>& M, const State<T>& s, T h, Accel<T>* ex, Acce
   im->lin = mul(R, cvt<T>(a0im));
 }
 
-// Euler advance of one substep with the accelerations `im`: activations, velocities, then positions with the NEW velocities
-template <class T, bool LOAD>
-QD_HD void integrate(const Model<T>& M, State<T>& s, const Accel<T>& im, T c0, T c1, T c2, T c3, T h) {
+// Euler advance of one substep with the accelerations `im`: activations, velocities, then positions with the NEW velocities.
+// In two parts because the first does not need the accelerations (the cooperative kernel runs it while it waits for them).
+template <class T>
+QD_HD void integrate_act(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3, T h) {
   // activations: explicit Euler on act_dot = (ctrl - act)/tau, computed from the pre-step act
   const T ht = h * M.inv_tau;
   s.a0 += ht * (c0 - s.a0); s.a1 += ht * (c1 - s.a1); s.a2 += ht * (c2 - s.a2); s.a3 += ht * (c3 - s.a3);
+}
+template <class T, bool LOAD>
+QD_HD void integrate_motion(State<T>& s, const Accel<T>& im, T h) {
   // velocities, then positions with the NEW velocities
   s.vx += h * im.lin.x; s.vy += h * im.lin.y; s.vz += h * im.lin.z;
   s.wx += h * im.ang.x; s.wy += h * im.ang.y; s.wz += h * im.ang.z;
@@ -616,6 +626,11 @@ QD_HD void integrate(const Model<T>& M, State<T>& s, const Accel<T>& im, T c0, T
     qn = frsq(nw * nw + nx * nx + ny * ny + nz * nz);
     s.qw = nw * qn; s.qx = nx * qn; s.qy = ny * qn; s.qz = nz * qn;
   }
+}
+template <class T, bool LOAD>
+QD_HD void integrate(const Model<T>& M, State<T>& s, const Accel<T>& im, T c0, T c1, T c2, T c3, T h) {
+  integrate_act(M, s, c0, c1, c2, c3, h);
+  integrate_motion<T, LOAD>(s, im, h);
 }
 
 // one physics substep (mj_step with nstep = 1): forward, then Euler advance.

@@ -719,6 +719,10 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
     const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
     if (role == 0) {
       f = mass_factor(e.M, tg, a.h);
+      // the part of the Euler step that does not wait for the accelerations: ctrl map and the activation filter
+      const float c0 = qclamp(0.1f + 0.9f * action.x, 0.f, 1.f), c1 = qclamp(0.1f + 0.9f * action.y, 0.f, 1.f);
+      const float c2 = qclamp(0.1f + 0.9f * action.z, 0.f, 1.f), c3 = qclamp(0.1f + 0.9f * action.w, 0.f, 1.f);
+      integrate_act(e.M, e.s, c0, c1, c2, c3, a.h);
     } else if (role == 1) {
       const Att<float> at = attitude(e.s);
       const Applied<float> ap = applied_wrench(e.M, e.s, at, tg);
@@ -767,8 +771,6 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
   int steps_post = 0;
   bool tr = false;
   if (role == 0 && live) {
-    float c0 = qclamp(0.1f + 0.9f * action.x, 0.f, 1.f), c1 = qclamp(0.1f + 0.9f * action.y, 0.f, 1.f);
-    float c2 = qclamp(0.1f + 0.9f * action.z, 0.f, 1.f), c3 = qclamp(0.1f + 0.9f * action.w, 0.f, 1.f);
     Applied<float> ap;
     {
       const float4 x0 = L.app[0][lane], x1 = L.app[1][lane], x2 = L.app[2][lane], x3 = L.app[3][lane], x4 = L.app[4][lane];
@@ -787,7 +789,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
     finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
     im.lin = mul(R, cvt<float>(a0im));
     w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
-    integrate<float, true>(e.M, e.s, im, c0, c1, c2, c3, a.h);
+    integrate_motion<float, true>(e.s, im, a.h);
     e.flags &= ~FLAG_ACC_STALE;
     e.num_steps += 1;
     steps_post = e.num_steps;
