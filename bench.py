@@ -167,7 +167,8 @@ def kernel_period_us(env, frag, launches=KERNEL_PERIOD_LAUNCHES):
     T = frag.T
     reps = max(1, launches // T)
     dev = env._dev
-    dev.step_fragment(frag.actions, frag.obs, frag.rewards, frag.truncated)   # capture (if new) + clock
+    for _ in range(2):   # a short fragment is captured the second time it is seen, a long one the first: both are past it now
+        dev.step_fragment(frag.actions, frag.obs, frag.rewards, frag.truncated)
     torch.cuda.synchronize()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
@@ -295,8 +296,7 @@ def main():
     for f in frags:
         f.actions.copy_(lo + (hi - lo) * torch.rand(f.actions.shape, generator=g, device=device, dtype=torch.float32))
     pending = [None, None]
-    state = {"cur": 0, "pos": 0, "gathers": 0, "graph_steps": 0, "direct_steps": 0, "total": 0}
-    graph_min = int(os.environ.get("QD_GRAPH_MIN_STEPS", "128"))
+    state = {"cur": 0, "pos": 0, "gathers": 0, "runs": [], "total": 0}
     if args.dry:
         def step_run(f, p, c):   # no env: stamp the slice so that the gather test can tell ranks and steps apart
             f.obs[p:p + c].fill_(float(rank + 1))
@@ -319,7 +319,7 @@ def main():
                 pending[cur] = None
             c = min(k_steps, T - pos)
             step_run(frags[cur], pos, c)
-            state["graph_steps" if c >= graph_min else "direct_steps"] += c
+            state["runs"].append(c)
             state["total"] += c
             k_steps -= c
             pos += c
@@ -359,7 +359,7 @@ def main():
 
     # Untimed preparation.  (1) clock ramp: a fresh process finds the GPU in a low power state and a 4 us kernel every 5 us
     # takes tens of ms to pull the shader clock up (measured: the same K steps are 2-12 % slower after 512 untimed steps than
-    # after 8192).  (2) rehearsal: the exact call sequence of the warmup + timed steps runs once on the same fragment buffers,
+    # after 8192).  (2) rehearsal: the exact call sequence of the warmup + timed steps runs twice on the same fragment buffers,
     # so every HIP graph the timed region replays already exists (a capture + instantiate costs ~20 us per node).  Both come
     # before the W warmup steps of the contract and are reported in config.clock_ramp_steps.
     if not args.dry:
@@ -372,15 +372,16 @@ def main():
                 sync()
         cur0 = state["cur"]
         if W + K <= 65536:
-            prepare()
-            run(K)
-            to_boundary()
-            state["cur"] = cur0      # at a boundary either buffer can be the current one: replay on the rehearsed ones
+            for _ in range(2):       # twice: qd_step_fragment captures a SHORT run the second time it sees it, a long one the first
+                prepare()
+                run(K)
+                to_boundary()
+                state["cur"] = cur0  # at a boundary either buffer can be the current one: replay on the rehearsed ones
         sync()
     prepare()
     ramp = state["total"] - W     # every untimed step before the W warmup steps
     fence()
-    state["graph_steps"] = state["direct_steps"] = 0
+    state["runs"] = []
     if not args.dry:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0 = time.perf_counter()
@@ -391,7 +392,8 @@ def main():
         ev1.record()
     fence()
     dt = time.perf_counter() - t0
-    timed_graph_steps, timed_direct_steps = state["graph_steps"], state["direct_steps"]
+    state["runs"] = list(state["runs"])      # the runs of the timed region (the gather measurements below add more)
+    timed_runs = list(state["runs"])
     if world > 1:
         tmax = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -442,9 +444,10 @@ def main():
                "config": {"workload": WORKLOADS[args.config] + "; trajectories written in place into [T=%d,N,...] fragments" % T +
                                       (" (their RCCL all-gather is reported separately in config.trajectory_all_gather)" if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": ("one k_step kernel launch per step, issued through qd_step_fragment (C ABI): %d of the %d timed steps as "
-                                     "replayed HIP graphs (runs of >= %d steps, captured before the timed region), %d launch by launch"
-                                     % (timed_graph_steps, K, graph_min, timed_direct_steps)),
+                          "launch": ("one step-kernel launch per step, issued through qd_step_fragment (C ABI), one call per run of steps inside a "
+                                     "fragment: the %d timed steps went out as %d run(s) of %s steps, each a replayed HIP graph captured during the "
+                                     "untimed rehearsal (QD_GRAPH_MIN_STEPS >= 2^30 would issue them launch by launch)"
+                                     % (K, len(timed_runs), "+".join(str(c) for c in timed_runs[:6]) + ("+..." if len(timed_runs) > 6 else ""))),
                           "precision": "float32 state / trigonometry / drag / integration, float64 inertia assembly and solves (load model)", "parallelism": "env-sharded x%d" % world,
                           "trajectory_all_gather": gather_info}}
         if args.dry:
@@ -515,14 +518,14 @@ def main():
                 for nn in (4096, 65536, 1048576, 4194304):
                     e2, alg2 = make_env(args.config, nn, 7, device)
                     (e2.vector_reset_tensor() if args.config != "config2" else e2.reset())
-                    a2 = lo + (hi - lo) * torch.rand((4, nn, 4), device=device, dtype=torch.float32)
-                    for _ in range(20):
-                        e2._dev.step(a2[0])
-                    p2 = stream_rate_us(e2, a2, launches=300 if nn <= 65536 else 60)
+                    T2 = 256 if nn <= 65536 else (64 if nn <= 1048576 else 16)      # fragments of <= 1.6 GB
+                    f2 = par.FragmentBuffers(T2, nn, e2._dev.D, device)
+                    f2.actions.copy_(lo + (hi - lo) * torch.rand(f2.actions.shape, device=device, dtype=torch.float32))
+                    p2, _ = kernel_period_us(e2, f2, launches=4 * T2)                # graph-replayed: the host is not in the loop
                     sweep.append({"envs": nn, "period_us": p2, "env_steps_per_s": nn / (p2 * 1e-6),
                                   "alg_GBps": ALG_BYTES[alg2] * nn / (p2 * 1e-6) / 1e9,
                                   "frac_hbm": ALG_BYTES[alg2] * nn / (p2 * 1e-6) / 1e9 / HBM_PEAK_GBS})
-                    del e2, a2
+                    del e2, f2
                     torch.cuda.empty_cache()
                 extras["env_count_sweep"] = sweep
                 # multi-step kernel (state in registers across T steps)

@@ -178,12 +178,13 @@ int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* senso
 int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
             uint8_t* truncated, void* stream);
 /* T consecutive qd_step launches (same kernels, same results: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N])
- * issued by ONE call.  T < 128 (QD_GRAPH_MIN_STEPS): launch by launch from a C loop.  Otherwise as ONE HIP graph: the
- * first call with a given (T, buffers) captures the launches, later calls replay them, so the per-step host launch path
- * (~4-5 us, the bound of qd_step at 4096 envs) is paid once per fragment; up to 8 graphs are kept per env (least recently
- * used replaced).  For rollout fragments whose actions are already on the device (replays, or a policy that wrote the
- * whole fragment).  Graphs are captured on a stream owned by the env and replayed in `stream`; qd_set_reference
- * invalidates them. */
+ * issued by ONE call.  Runs of >= 128 steps (QD_GRAPH_MIN_STEPS) go out as ONE HIP graph: the first call with a given
+ * (T, buffers) captures the launches, later calls replay them, so the per-step host launch path (~4-5 us, the bound of
+ * qd_step at 4096 envs) is paid once per fragment.  A shorter run is issued launch by launch the first time its (T, buffers)
+ * are seen, captured the second time and replayed from then on (a capture costs ~20 us per node, a replay 10-16 us).  Up to
+ * 8 graphs are kept per env (least recently used replaced); QD_GRAPH_MIN_STEPS >= 2^30 switches graphs off.  For rollout
+ * fragments whose actions are already on the device (replays, or a policy that wrote the whole fragment).  Graphs are
+ * captured on a stream owned by the env and replayed in `stream`; qd_set_reference invalidates them. */
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
 /* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
  * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */

@@ -1766,10 +1766,29 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   const int n = env->ka.n;
   const size_t D = (size_t)env->D;
-  // Short fragments are issued launch by launch from this loop: capturing + instantiating a graph costs ~20 us per node
-  // once (370 us for 20 steps, measured in round 1 inside a timed region) and a replay has a fixed 10-16 us, while a
-  // direct launch costs the host 3.5-4 us, i.e. about the kernel's own period -- below ~128 steps the graph never pays.
-  if (T < qd_graph_min_steps()) {
+  qd_env::Frag* fr = nullptr;
+  for (auto& f : env->frag)
+    if (f.T == T && f.actions == actions && f.obs == obs && f.reward == reward && f.trunc == truncated) fr = &f;
+  // A graph costs ~20 us per node to capture and instantiate (370 us for 20 steps, measured in round 1 inside a timed region)
+  // and 10-16 us per replay; a direct launch costs the host 3.5-5 us, about the kernel's own period.  So: long runs are
+  // captured at first sight; a short run (< 128 steps) is issued launch by launch the first time these buffers and this
+  // length are seen, captured the second time (a caller that repeats it will repeat it again) and replayed from then on.
+  const bool known = fr != nullptr, never = qd_graph_min_steps() >= (1 << 30);   // QD_GRAPH_MIN_STEPS >= 2^30: no graphs at all (counter passes)
+  if (!(fr && fr->exec) && T < qd_graph_min_steps() && (!known || never)) {
+    if (never) {
+      for (int t = 0; t < T; t++) {
+        const int rc = qd_step(env, actions + (size_t)t * n * 4, (int64_t)n * 4, obs + (size_t)t * n * D, reward + (size_t)t * n,
+                               truncated + (size_t)t * n, stream);
+        if (rc != QD_OK) return rc;
+      }
+      return QD_OK;
+    }
+    fr = &env->frag[0];
+    for (auto& f : env->frag)
+      if (f.T == 0) { fr = &f; break; } else if (f.used < fr->used) fr = &f;   // a free slot, else the least recently used
+    if (fr->exec) { (void)hipGraphExecDestroy(fr->exec); fr->exec = nullptr; }
+    fr->actions = actions; fr->obs = obs; fr->reward = reward; fr->trunc = truncated; fr->T = T;   // remembered, not captured
+    fr->used = ++env->frag_clock;
     for (int t = 0; t < T; t++) {
       const int rc = qd_step(env, actions + (size_t)t * n * 4, (int64_t)n * 4, obs + (size_t)t * n * D, reward + (size_t)t * n,
                              truncated + (size_t)t * n, stream);
@@ -1777,15 +1796,14 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
     }
     return QD_OK;
   }
-  qd_env::Frag* fr = nullptr;
-  for (auto& f : env->frag)
-    if (f.exec && f.T == T && f.actions == actions && f.obs == obs && f.reward == reward && f.trunc == truncated) fr = &f;
-  if (!fr) {
+  if (!(fr && fr->exec)) {
     // capture on a private stream (the caller's may be the legacy default stream, which cannot be captured) ...
     if (!env->frag_stream) QD_HIP(hipStreamCreateWithFlags(&env->frag_stream, hipStreamNonBlocking));
-    fr = &env->frag[0];
-    for (auto& f : env->frag)
-      if (f.T == 0 || !f.exec) { fr = &f; break; } else if (f.used < fr->used) fr = &f;   // a free slot, else the least recently used
+    if (!fr) {
+      fr = &env->frag[0];
+      for (auto& f : env->frag)
+        if (f.T == 0) { fr = &f; break; } else if (f.used < fr->used) fr = &f;   // a free slot, else the least recently used
+    }
     if (fr->exec) { (void)hipGraphExecDestroy(fr->exec); fr->exec = nullptr; }
     fr->T = 0;
     QD_HIP(hipStreamBeginCapture(env->frag_stream, hipStreamCaptureModeThreadLocal));

@@ -31,12 +31,10 @@ for rep in range(50):
 acc = np.array(acc).reshape(-1, 3, 15)
 med = np.median(acc, axis=0)
 names = ["start", "loads arrived", "phase 1 done", "barrier 1 passed", "phase 2 done", "barrier 2 passed", "phase 3 done",
-         "barrier 3 passed", "flush issued", "stores drained", "A: hand-over read", "A: rhs reduced", "A: accel solved", "A: integrated",
-         "A: state published"]
+         "barrier 3 passed", "flush issued", "stores drained"]
 print("median cycles since the workgroup's first wave started (waves A / B / C):")
 for k, nm in enumerate(names):
     print("  %-18s %7.0f %7.0f %7.0f" % (nm, med[0, k], med[1, k], med[2, k]))
 one = acc[-64:]
 tot = one[:, :, 9].max(axis=1)
-print('wave A inside phase 2 (median):', ' '.join('%s %d' % (n, med[0, 10 + k]) for k, n in enumerate(['read', 'rhs', 'solved', 'integrated', 'published'])))
 print("slowest workgroup of the last launch:", one[np.argmax(tot)].astype(int).tolist())

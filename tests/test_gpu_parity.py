@@ -966,6 +966,31 @@ def test_step_fragment_graph_replay_equals_steps(qd):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6)
 
 
+def test_step_fragment_policies_long_and_short_runs(qd):
+    """qd_step_fragment's three ways of issuing a run -- launch by launch (a short run seen for the first time), capture (a long
+    run at once, a short one at its second sighting) and replay -- all equal T x qd_step, also with QD_GRAPH_MIN_STEPS's default
+    boundary (128) in between"""
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    n = 64
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=40, auto_reset=True)
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    e1.vector_reset_tensor(); e2.vector_reset_tensor()
+    for T in (130, 20):
+        acts = torch.rand((T, n, 4), device="cuda")
+        obs = torch.empty((T, n, 22), device="cuda"); rew = torch.empty((T, n), device="cuda")
+        tr = torch.empty((T, n), dtype=torch.uint8, device="cuda")
+        for rep in range(3):          # T = 130: capture, replay, replay; T = 20: direct, capture, replay
+            e1.step_fragment_tensor(acts, obs, rew, tr)
+            for t in range(T):
+                o, r, trn = e2.vector_step_tensor(acts[t])
+                np.testing.assert_allclose(obs[t].cpu().numpy(), o.cpu().numpy(), atol=1e-6, err_msg="T %d rep %d t %d" % (T, rep, t))
+                np.testing.assert_allclose(rew[t].cpu().numpy(), r.cpu().numpy(), atol=1e-6)
+                assert torch.equal(tr[t], trn)
+
+
 @pytest.mark.parametrize("n", [1, 63, 65, 4097, 16384, 16385, 65535, 65536, 98303, 98304, 131073])
 def test_ragged_and_threshold_batch_sizes(qd, n):
     """batch sizes that are not multiples of the wavefront / workgroup, and the sizes at which the library switches launch

@@ -18,14 +18,14 @@ trace)
   cp $(find $RAW/def -name "*_kernel_stats.csv" | head -1) $OUT/r02_default_kernel_stats.csv
   ;;
 pmc4096)
-  export QD_GRAPH_MIN_STEPS=100000000 QD_BENCH_RAMP_STEPS=1024
+  export QD_GRAPH_MIN_STEPS=2000000000 QD_BENCH_RAMP_STEPS=1024
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/p0 -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/pf -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/pw -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   python3 profiles/summarize.py r02_pmc_n4096 $RAW/p0 --kernel k_step_coop --out $OUT --pmc fetch=$RAW/pf --pmc write=$RAW/pw
   ;;
 pmc1m)
-  export QD_GRAPH_MIN_STEPS=100000000 QD_BENCH_RAMP_STEPS=64
+  export QD_GRAPH_MIN_STEPS=2000000000 QD_BENCH_RAMP_STEPS=64
   A="--envs 1048576 --fragment 8 --steps 128 --warmup 16"
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/m0 -- python3 bench.py $A $B > /dev/null
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/mf -- python3 bench.py $A $B > /dev/null
@@ -33,7 +33,7 @@ pmc1m)
   python3 profiles/summarize.py r02_pmc_n1m $RAW/m0 --kernel "k_step<" --out $OUT --pmc fetch=$RAW/mf --pmc write=$RAW/mw
   ;;
 sq)
-  export QD_GRAPH_MIN_STEPS=100000000 QD_BENCH_RAMP_STEPS=1024
+  export QD_GRAPH_MIN_STEPS=2000000000 QD_BENCH_RAMP_STEPS=1024
   C="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/q0 -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $RAW/q1 -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
