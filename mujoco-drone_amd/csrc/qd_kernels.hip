@@ -245,7 +245,7 @@ __device__ __forceinline__ void sample_episode(const KArgs& a, int i, uint32_t e
 // NEXT episode ready in the arena: episode e lives in slot e & 1 (planes NX* / NY*); a truncating lane only
 // loads its entry.  The sample for (env, episode) is a pure function of the Philox counter, so results do
 // not depend on who computes it or when.  Protocol (no intra-launch synchronisation):
-//   explicit reset (k_reset)  : draws episode e inline, and leaves sample(e+1) in its slot for the new counter e+1
+//   explicit reset (k_reset)  : draws episode e inline, leaves sample(e+1) in its slot for the new counter e+1, adds 1 to need[w]
 //   sampler, any step launch  : if need[w] == 0 for its 64 envs -> exit.  Otherwise, with E = AUX.episode as it reads it,
 //                               makes slot (E+1) & 1 hold sample(E+1) and subtracts the request count it had read
 //   physics, on truncation    : in episode e, if slot e & 1 is valid with tag e -> take it, mark it consumed and add 1
@@ -327,8 +327,13 @@ __device__ __forceinline__ void resample(const KArgs& a, int i, EnvRegs& e, bool
   sample_episode<LOAD>(a, i, e.episode, e.s);
   e.episode += 1u;
   e.num_steps = 0;
-  // the new counter's own entry (samplers only ever fill the one after it); both stages: a reset kernel is not in a hurry
-  if (a.use_pool && !pool_fill<LOAD>(a, i, e.episode)) pool_fill<LOAD>(a, i, e.episode);
+  // the new counter's own entry (samplers only ever fill the one after it); both stages: a reset kernel is not in a hurry.
+  // And a request, so that the next step launch's samplers prepare the episode after this one: without it the env's second
+  // truncation after every explicit reset found no entry and sampled inline (one in seven resets of the regen-every-1024 bench).
+  if (a.use_pool) {
+    if (!pool_fill<LOAD>(a, i, e.episode)) pool_fill<LOAD>(a, i, e.episode);
+    pool_request(a, i);
+  }
   if (eager_sensor) refresh_sensor<LOAD>(a, e);
   else e.flags |= FLAG_ACC_STALE;
 }
