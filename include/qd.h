@@ -186,6 +186,11 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
  * fragments whose actions are already on the device (replays, or a policy that wrote the whole fragment).  Graphs are
  * captured on a stream owned by the env and replayed in `stream`; qd_set_reference invalidates them. */
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
+/* How the in-kernel resets (auto_reset) since qd_init got their new state: counters[0] = served by the reset pool (an entry
+ * pre-sampled by the sampler workgroups of earlier launches), counters[1] = sampled inline by the truncating lane (pool off,
+ * or no entry yet).  Same results either way; inline sampling is what the pool exists to keep off the step's critical path.
+ * counters: 2 x uint32 in device memory, written in stream order. */
+int qd_pool_counters(qd_env* env, uint32_t* counters, void* stream);
 /* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
  * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated,

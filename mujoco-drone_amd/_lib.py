@@ -101,6 +101,7 @@ SIGNATURES = {
     "qd_step": (_I, [_VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "qd_rollout": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "qd_step_fragment": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "qd_pool_counters": (_I, [_VP, _VP, _VP]),
     "qd_pid_reset": (_I, [_VP, _VP, _VP]),
     "qd_pid_action": (_I, [_VP, _VP, _VP]),
     "qd_rollout_pid": (_I, [_VP, _I, _VP, _VP, _VP, _VP, _VP]),

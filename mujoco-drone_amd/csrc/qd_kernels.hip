@@ -49,6 +49,7 @@ enum Group {
   NUM_GROUPS
 };
 constexpr int RAW_PLANES = 6;
+constexpr int POOL_STAT_WORDS = 64;   // behind the refill counters: [0] in-kernel resets served by the pool, [1] sampled inline (qd_pool_counters)
 constexpr int PAD = 256;
 
 struct KArgs {
@@ -88,6 +89,10 @@ constexpr uint32_t FLAG_ACC_STALE = 1u;
 // one lane asks for a refill of its env's reset-pool entries (see "reset pool"; the counter covers the lane's 64-env group)
 __device__ __forceinline__ void pool_request(const KArgs& a, int i) {
   __hip_atomic_fetch_add(a.need + (i >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// bookkeeping of how in-kernel resets got their state (a handful of atomics per launch: only truncating lanes come here)
+__device__ __forceinline__ void pool_count(const KArgs& a, bool taken) {
+  __hip_atomic_fetch_add(a.need + (a.npad >> 6) + (taken ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Compile-time specialisations of the fused step for the configurations the reference trains with; every other
@@ -388,6 +393,7 @@ __device__ __forceinline__ void reset_in_step(const KArgs& a, int i, EnvRegs& e)
       taken = true;
     }
     pool_request(a, i);
+    pool_count(a, taken);
   }
   if (!taken) sample_episode<LOAD>(a, i, e.episode, e.s);
   reset_bookkeeping(e.s, e.episode, e.num_steps);
@@ -833,6 +839,7 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float
       if (a.use_pool) {
         if (taken) a.g[(pool_slot(consumed) + 4) * a.npad + i] = make_float4(nx4.x, nx4.y, __uint_as_float(0u), 0.f);
         pool_request(a, i);
+        pool_count(a, taken);
       }
     }
     L.flag[lane] = rst ? 1u : 0u;
@@ -1207,6 +1214,7 @@ __global__ __launch_bounds__(64) void k_init_state(KArgs a, int full) {
     g[G_NX4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
     g[G_NY4 * np + i] = make_float4(0.f, 0.f, __uint_as_float(0u), 0.f);
     if ((i & 63) == 0) a.need[i >> 6] = 1u;   // empty pool: the first step launch's samplers fill it
+    if (i == 0) { a.need[(a.npad >> 6) + 0] = 0u; a.need[(a.npad >> 6) + 1] = 0u; }
     PidState<float> c;
     pid_reset(c);
     store_pid(a, i, c);
@@ -1487,7 +1495,7 @@ static inline int npad_of(int n) { return (n + PAD - 1) / PAD * PAD; }
 size_t qd_arena_bytes(int num_envs) {
   if (num_envs <= 0) return 0;
   const size_t np = (size_t)npad_of(num_envs);
-  return np * ((size_t)NUM_GROUPS * sizeof(float4) + (size_t)RAW_PLANES * sizeof(double)) + (np / 64) * sizeof(uint32_t);
+  return np * ((size_t)NUM_GROUPS * sizeof(float4) + (size_t)RAW_PLANES * sizeof(double)) + (np / 64 + POOL_STAT_WORDS) * sizeof(uint32_t);
 }
 
 static int needs_load_reward(int k) {
@@ -1831,6 +1839,13 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
   // ... and replay in the caller's stream, in order with everything else there.  (Running the graph on the private stream
   // between cross-stream event waits costs 0.9 us PER KERNEL on this runtime: 5.9 instead of 5.0 us per step.)
   QD_HIP(hipGraphLaunch(fr->exec, S(stream)));
+  return QD_OK;
+}
+
+int qd_pool_counters(qd_env* env, uint32_t* counters, void* stream) {
+  QD_NEED(env);
+  if (!counters) return fail(QD_ERR_INVALID, "null output");
+  QD_HIP(hipMemcpyAsync(counters, env->ka.need + (env->ka.npad >> 6), 2 * sizeof(uint32_t), hipMemcpyDeviceToDevice, S(stream)));
   return QD_OK;
 }
 

@@ -154,6 +154,13 @@ class DeviceEnv:
         L.check(self.lib.qd_step_fragment(self.handle, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(truncated), self._stream()))
         return obs, reward, truncated
 
+    def pool_counters(self):
+        """(in-kernel resets served by the reset pool, in-kernel resets sampled inline) since construction"""
+        out = torch.zeros(2, dtype=torch.int32, device=self.device)
+        L.check(self.lib.qd_pool_counters(self.handle, _ptr(out), self._stream()))
+        taken, inline = (int(x) & 0xFFFFFFFF for x in out.cpu().tolist())
+        return taken, inline
+
     def rollout(self, actions, obs=None, reward=None, truncated=None):
         """actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N] in one launch."""
         actions = self._f32(actions, tuple(actions.shape))

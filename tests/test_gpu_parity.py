@@ -966,6 +966,34 @@ def test_step_fragment_graph_replay_equals_steps(qd):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), atol=1e-6)
 
 
+@pytest.mark.parametrize("config", ["config3", "config5"])
+def test_reset_pool_serves_the_in_kernel_resets(qd, config):
+    """The reset pool is a performance device with a protocol spread over launches (explicit resets leave the next entry and a
+    request, samplers fill the entry after the counter they read, truncating lanes consume and request): a flaw in it does not
+    change results -- a lane that finds no entry samples inline -- it only puts the sampling back on the step's critical path.
+    So its effect is checked by counting: over BASELINE-shaped runs (regen + full reset every 1024 steps for config 3) all but
+    a few of the in-kernel resets must have been served by the pool.  (Round 2's first version of the protocol sampled every
+    env's second episode after each full reset inline: one in seven.)"""
+    import bench
+    n = 4096 if config == "config3" else 8192
+    env, _ = bench.make_env(config, n, 42, "cuda:0")
+    env.vector_reset_tensor()
+    T = 512
+    g = torch.Generator(device="cuda").manual_seed(1)
+    acts = torch.rand((T, n, 4), generator=g, device="cuda")
+    obs = torch.empty((T, n, env._dev.D), device="cuda"); rew = torch.empty((T, n), device="cuda")
+    tr = torch.empty((T, n), dtype=torch.uint8, device="cuda")
+    resets = 0
+    for k in range(6):                       # 3072 steps: three regen periods of config 3
+        env.step_fragment_tensor(acts, obs, rew, tr)
+        resets += int(tr.sum())
+    taken, inline = env._dev.pool_counters()
+    print("%s: %d in-kernel resets, %d from the pool, %d sampled inline" % (config, taken + inline, taken, inline))
+    assert taken + inline > 20000
+    assert inline <= 0.01 * (taken + inline)
+    assert taken + inline <= resets          # the regen steps flag every env truncated without an in-kernel reset
+
+
 def test_step_fragment_policies_long_and_short_runs(qd):
     """qd_step_fragment's three ways of issuing a run -- launch by launch (a short run seen for the first time), capture (a long
     run at once, a short one at its second sighting) and replay -- all equal T x qd_step, also with QD_GRAPH_MIN_STEPS's default
