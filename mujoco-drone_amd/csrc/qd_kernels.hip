@@ -290,10 +290,9 @@ __device__ __forceinline__ void pool_store(const KArgs& a, int i, uint32_t episo
 // affine form at that state (~1300).  One stage per call: an entry is prepared an episode ahead, so there is no hurry, and a
 // sampler wave that did both in one launch would outlast the physics waves it is meant to hide behind.
 template <bool LOAD>
-__device__ __forceinline__ bool pool_fill(const KArgs& a, int i, uint32_t next) {
+__device__ __forceinline__ bool pool_fill(const KArgs& a, int i, uint32_t next, float4 nx4 /* the slot's tag plane */) {
   float4* g = a.g;
   const int np = a.npad, base = pool_slot(next);
-  const float4 nx4 = g[(base + 4) * np + i];
   const uint32_t stage = __float_as_uint(nx4.y) == next ? __float_as_uint(nx4.z) : 0u;
   const uint32_t want = (LOAD && a.obs_needs_acc) ? POOL_FULL : POOL_STATE;
   if (stage >= want) return true;
@@ -323,6 +322,10 @@ __device__ __forceinline__ bool pool_fill(const KArgs& a, int i, uint32_t next) 
   }
   return true;
 }
+template <bool LOAD>
+__device__ __forceinline__ bool pool_fill(const KArgs& a, int i, uint32_t next) {
+  return pool_fill<LOAD>(a, i, next, a.g[(pool_slot(next) + 4) * a.npad + i]);
+}
 
 // sample_state for this lane's env, episode counter advanced.  eager_sensor: run mj_forward's sensor
 // part now (reset kernels); otherwise only mark the stored reading stale -- it is recomputed by the
@@ -351,7 +354,13 @@ __device__ __forceinline__ void sampler_wave(const KArgs& a, int j) {
   const uint32_t pending = __hip_atomic_load(a.need + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (pending == 0u) return;
   bool done = true;
-  if (j < a.n) done = pool_fill<LOAD>(a, j, __float_as_uint(a.g[G_AUX * a.npad + j].z) + 1u);
+  if (j < a.n) {
+    // the counter and both slots' tag planes in ONE round trip (which slot is the next episode's depends on the counter): a
+    // refilling sampler wave is about as long as a physics wave, and a dependent load here is ~1000 cycles of it
+    const float4 aux = a.g[G_AUX * a.npad + j], tx = a.g[G_NX4 * a.npad + j], ty = a.g[G_NY4 * a.npad + j];
+    const uint32_t next = __float_as_uint(aux.z) + 1u;
+    done = pool_fill<LOAD>(a, j, next, (next & 1u) ? ty : tx);
+  }
   // entries that still lack a stage keep the request alive: the next launch's sampler comes back for them
   if (__all(done ? 1 : 0) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_sub(a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
