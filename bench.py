@@ -232,7 +232,9 @@ def launch_ranks(n_ranks, argv):
             raise
         out0_file.seek(0)
         out0 = out0_file.read().decode()
-    sys.stdout.write(out0)
+    # stdout carries the JSON line and nothing else (gloo, for one, announces its connections on rank 0's stdout)
+    for ln in out0.splitlines():
+        (sys.stdout if ln.startswith("{") else sys.stderr).write(ln + "\n")
     sys.stdout.flush()
     bad = [(r, c) for r, c in enumerate(codes) if c != 0]
     if bad:
