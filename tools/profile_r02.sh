@@ -5,11 +5,9 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r02; RAW=/tmp/prof_raw; mkdir -p $OUT $RAW
 B="--no-extras --no-cpu-baseline"
-small="QD_BENCH_RAMP_STEPS=2048"
 case "$1" in
 trace)
   # the driver's command and the default command, kernel trace + stats
-  env QD_BENCH_RAMP_STEPS=8192 true
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/s20 -- python3 bench.py --steps 20 --warmup 5 $B > $OUT/bench_s20_profiled.json
   python3 profiles/summarize.py r02_s20_n4096 $RAW/s20 --kernel k_step_coop --out $OUT
   cp $(find $RAW/s20 -name "*_kernel_stats.csv" | head -1) $OUT/r02_s20_kernel_stats.csv
