@@ -26,9 +26,9 @@ for rep in range(50):
         env._dev.step(a[i % 8])
     torch.cuda.synchronize()
     assert lib.qd_debug_read_cstamps(buf) == 0
-    st = np.array(buf[:], dtype=np.int64).reshape(64, 3, 16)[:, :, :15]
+    st = np.array(buf[:], dtype=np.int64).reshape(64, 3, 16)[:, :, :10]
     acc.append(st - st[:, :, :1].min(axis=1, keepdims=True))      # relative to the workgroup's first wave start
-acc = np.array(acc).reshape(-1, 3, 15)
+acc = np.array(acc).reshape(-1, 3, 10)
 med = np.median(acc, axis=0)
 names = ["start", "loads arrived", "phase 1 done", "barrier 1 passed", "phase 2 done", "barrier 2 passed", "phase 3 done",
          "barrier 3 passed", "flush issued", "stores drained"]
