@@ -169,3 +169,35 @@ def test_arena_plane_table_matches_the_kernel_source():
     body = re.sub(r"//[^\n]*", "", body)
     names = [m.replace("G_", "") for m in re.findall(r"\b(G_[A-Z0-9]+)\b", body)]
     assert names == ARENA_PLANES
+
+
+def test_env_context_like_config_without_device(monkeypatch):
+    """RLlib hands the env an EnvContext: a dict with worker bookkeeping ATTRIBUTES.  The reference reads `worker_index` once with
+    getattr (viewer decision, BaseDroneEnv.py:62) and once with config.get (the seed, :113) -- so the attribute never reaches the
+    seed (quirk C-4) while a dict key does; the constructor must accept such an object and behave the same up to the device
+    hand-off (the GPU half of this contract is tests/test_gpu_rllib_contract.py)"""
+    from mujoco_drone_amd.environments import BaseDroneEnv as B
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    seen = {}
+
+    class FakeDev:
+        def __init__(self, cfg, device):
+            seen["cfg"] = cfg
+            raise InterruptedError  # stop before any device use
+
+    class EnvContext(dict):
+        def __init__(self, cfg, worker_index, vector_index=0, remote=False, num_workers=8):
+            dict.__init__(self, cfg)
+            self.worker_index, self.vector_index, self.remote, self.num_workers = worker_index, vector_index, remote, num_workers
+
+    monkeypatch.setattr(B, "DeviceEnv", FakeDev)
+    cfg = dict(B.base_config, num_drones=64, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=0.2, max_steps=1024, regen_env_at_steps=1024)
+    seeds = []
+    for ctx in (EnvContext(cfg, 1), EnvContext(cfg, 7), EnvContext(dict(cfg, worker_index=7), 7)):
+        with pytest.raises(InterruptedError):
+            LocalFrameRPYParamsEnv(ctx)
+        seeds.append(int(seen["cfg"].seed))
+        assert seen["cfg"].num_envs == 64 and seen["cfg"].max_steps == 1024
+    assert seeds == [42, 42, 50]
