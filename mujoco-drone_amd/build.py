@@ -23,6 +23,9 @@ CSRC = os.path.join(PKG_DIR, "csrc")
 INCLUDE = os.path.normpath(os.path.join(PKG_DIR, "..", "include"))
 LIB = os.environ.get("QD_LIB") or os.path.join(PKG_DIR, "libqd.so")  # QD_LIB: diagnostic builds only
 ARCH = "gfx950"
+# the step kernels' leading scalar arguments arrive in SGPRs at wave launch instead of through a kernarg fetch at the top of the
+# kernel (csrc/qd_kernels.hip, StepKernarg); part of the source hash like the sources themselves
+CODEGEN_FLAGS = ("-mllvm", "-amdgpu-kernarg-preload-count=5")
 HASH_TAG = b"QD_SOURCE_HASH="
 
 
@@ -54,7 +57,7 @@ def source_hash(extra_flags=()):
         h.update(b"\0")
         h.update(open(d, "rb").read())
         h.update(b"\0")
-    h.update(" ".join(extra_flags).encode())
+    h.update(" ".join(CODEGEN_FLAGS + tuple(extra_flags)).encode())
     return h.hexdigest()
 
 
@@ -94,7 +97,7 @@ def build_library(force=False, verbose=False):
     extra = _extra_flags()
     tmp = LIB + ".tmp.%d" % os.getpid()
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc",
-           "-Wno-unused-result", '-DQD_SOURCE_HASH="%s"' % source_hash(extra), *extra, "-o", tmp] + sources()
+           "-Wno-unused-result", *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="%s"' % source_hash(extra), *extra, "-o", tmp] + sources()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
         print(" ".join(cmd), flush=True)
@@ -107,5 +110,22 @@ def build_library(force=False, verbose=False):
     return LIB
 
 
+def build_variant(name, flags=()):
+    """A diagnostic build beside the tests (tests/_build/libqd_<name>.so): the product's recipe plus `flags`, e.g.
+    build_variant("diag", ["-DQD_STAMPS"]).  Loaded with QD_LIB=<path> (exempt from the source-hash check)."""
+    out_dir = os.path.join(os.path.dirname(PKG_DIR), "tests", "_build")
+    os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, "libqd_%s.so" % name)
+    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
+           *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="variant:%s"' % name, *flags, "-o", out] + sources()
+    subprocess.check_call(cmd)
+    return out
+
+
 if __name__ == "__main__":
-    print(build_library(force="--force" in sys.argv, verbose="-v" in sys.argv))
+    # python -m mujoco_drone_amd.build [--force] [-v]   |   python mujoco-drone_amd/build.py --variant diag -DQD_STAMPS
+    if "--variant" in sys.argv:
+        k = sys.argv.index("--variant")
+        print(build_variant(sys.argv[k + 1], sys.argv[k + 2:]))
+    else:
+        print(build_library(force="--force" in sys.argv, verbose="-v" in sys.argv))

@@ -147,9 +147,7 @@ __device__ __forceinline__ void moving_reference(const KArgs& a, int i, int k, f
 // FOLD = true: planes M3..M6 (fluid coefficients) are not fetched but re-folded from M0..M2 in float32; used by
 // the 256-thread (HBM-bound) step kernels, where 64 bytes less per env-step matter more than ~90 instructions.
 template <bool LOAD, bool WITH_ACC = true, bool FOLD = false>
-__device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
-  const float4* g = a.g;
-  const int np = a.npad;
+__device__ __forceinline__ void load_env_planes(const float4* g, int np, int i, EnvRegs& e) {
   const float4 pos = g[G_POS * np + i], qt = g[G_QUAT * np + i], vel = g[G_VEL * np + i], ang = g[G_ANG * np + i];
   const float4 act = g[G_ACT * np + i], aux = g[G_AUX * np + i];
   const float4 acc = WITH_ACC ? g[G_ACC * np + i] : make_float4(0.f, 0.f, 0.f, 0.f);
@@ -188,14 +186,23 @@ __device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
     }
   }
   e.par[0] = p0.x; e.par[1] = p0.y; e.par[2] = p0.z; e.par[3] = p0.w; e.par[4] = p1.x; e.par[5] = p1.y;
+}
+// the env's reference point: the one thing of its registers that depends on launch arguments other than the arena
+__device__ __forceinline__ void load_env_ref(const KArgs& a, int i, EnvRegs& e) {
   if (a.ref_mode != QD_REF_STATIC) {
     moving_reference(a, i, e.num_steps, e.ref);
   } else if (a.per_env_ref) {
-    const float4 r = g[G_REF * np + i];
+    const float4 r = a.g[G_REF * a.npad + i];
     e.ref[0] = r.x; e.ref[1] = r.y; e.ref[2] = r.z; e.ref[3] = r.w;
   } else {
     e.ref[0] = a.ref[0]; e.ref[1] = a.ref[1]; e.ref[2] = a.ref[2]; e.ref[3] = a.ref[3];
   }
+}
+
+template <bool LOAD, bool WITH_ACC = true, bool FOLD = false>
+__device__ __forceinline__ void load_env(const KArgs& a, int i, EnvRegs& e) {
+  load_env_planes<LOAD, WITH_ACC, FOLD>(a.g, a.npad, i, e);
+  load_env_ref(a, i, e);
 }
 
 // everything of store_env but the accelerometer plane
@@ -575,16 +582,59 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   (void)NS;
 }
 
+// Arguments of the step kernels, as they lie in the kernarg segment (same member order as k_step_wide's / k_step_coop's parameters).
+// The leading scalars repeat members of the struct: they are all the first round of global loads needs (arena base, plane
+// stride, env count, role of the workgroup), and as separate arguments ahead of the struct they are preloaded into SGPRs at
+// wave launch (-mllvm -amdgpu-kernarg-preload-count, build.py): those loads leave at once instead of one memory round trip
+// later, behind the fetch of the kernarg segment (about as slow as they are: every launch starts with cold caches).
+// Measured on one box, alternating runs, config 3: 4.25 -> 4.02 us per step at 4096 envs (k_step_coop), 78.8 -> 70.7 us at 2^20
+// envs (k_step<true,256,1>, which also loses its last 36 bytes of scratch); the single-wave 64-thread kernels gained nothing
+// in any arrangement tried (config 5 at 8192 envs: 5.42 -> 5.47 ... 5.65 us) and keep their struct-first signature (k_step).
+struct StepKernarg {
+  float4* g;
+  const float* actions;
+  int npad, n, main_blocks;
+  KArgs a;
+  float* obs;
+  float* reward;
+  uint8_t* trunc;
+};
+// The KArgs of a step launch, read from the kernarg segment at the point of the call and not before.  A reference to the
+// struct parameter itself is lowered to scalar loads at the top of the kernel plus register copies that wait for them there,
+// ahead of everything; the empty asm hides the address from the optimiser and keeps the global loads issued so far ahead of
+// these scalar loads.  (Tried and slower: the scalar loads first and only the wait deferred -- 4.09 us; every member pinned in
+// one batch instead of sunk into the branches that use it -- same at 4096 envs, 3 % slower for config 5.)
+__device__ __forceinline__ KArgs step_kargs(float4* g, int npad, int n, int main_blocks) {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  kptr kp = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+  asm volatile("" : "+s"(kp)::"memory");
+  static_assert(sizeof(KArgs) % 4 == 0 && offsetof(StepKernarg, a) % 4 == 0, "KArgs is copied from the kernarg segment in dwords");
+  const __attribute__((address_space(4))) uint32_t* w = (const __attribute__((address_space(4))) uint32_t*)(kp + offsetof(StepKernarg, a));
+  constexpr unsigned NW = sizeof(KArgs) / 4;
+  uint32_t u[NW];
+#pragma unroll
+  for (unsigned k = 0; k < NW; k++) u[k] = w[k];   // only the members the kernel reads survive as scalar loads
+  KArgs a;
+  __builtin_memcpy(&a, u, sizeof(KArgs));
+  a.g = g;
+  a.npad = npad;
+  a.n = n;
+  a.main_blocks = main_blocks;
+  return a;
+}
+
 // The 256-thread variant (>= 65536 envs, the chip is full) is capped at 256 registers so that TWO waves share a
 // SIMD and hide each other's memory latency; with the substep count known at compile time the specialised
 // instantiations fit with a few dwords of scratch.  The 64-thread variant (small batches: one wave per SIMD
 // anyway) keeps the whole register file.
-template <bool LOAD, int BLOCK, int SPEC>
-__global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 : 1)) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
-                                                float* __restrict__ reward, uint8_t* __restrict__ trunc) {
+// DEFER: the kernel has the StepKernarg signature (k_step_wide); else `a_in` is the kernel's own struct parameter, read at the top
+template <bool LOAD, int BLOCK, int SPEC, bool DEFER>
+__device__ __forceinline__ void step_body(float4* g_pre, const float* __restrict__ actions, int npad_pre, int n_pre, int main_blocks_pre,
+                                          const KArgs& a_in, float* __restrict__ obs, float* __restrict__ reward,
+                                          uint8_t* __restrict__ trunc) {
   __shared__ float tile[(BLOCK / 64) * OBS_LDS_FLOATS];
-  if (BLOCK == 64 && (int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool"); 64-thread launches only
-    sampler_wave<LOAD>(a, ((int)blockIdx.x - a.main_blocks) * BLOCK + threadIdx.x);
+  if (BLOCK == 64 && (int)blockIdx.x >= a_in.main_blocks) {  // sampler workgroup (see "reset pool"); 64-thread launches only
+    sampler_wave<LOAD>(a_in, ((int)blockIdx.x - a_in.main_blocks) * BLOCK + threadIdx.x);
     return;
   }
   const int i = blockIdx.x * BLOCK + threadIdx.x;
@@ -595,10 +645,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_rstamps[blockIdx.x * 2] = __builtin_amdgcn_s_memrealtime();
 #endif
   QD_STAMP(0);
+  EnvRegs e;
+  float4 action = make_float4(0.f, 0.f, 0.f, 0.f);
+  if constexpr (DEFER) {
+    // lanes past the batch fetch the last env's planes: an unconditional fetch keeps the loads, the argument fetch and the
+    // first arithmetic in one basic block, in that order
+    const int il = i < n_pre ? i : n_pre - 1;
+    load_env_planes<LOAD, false, true>(g_pre, npad_pre, il, e);
+    action = reinterpret_cast<const float4*>(actions)[il];
+  }
+  const KArgs a = DEFER ? step_kargs(g_pre, npad_pre, n_pre, main_blocks_pre) : a_in;
   if (i < a.n) {
-    EnvRegs e;
-    load_env<LOAD, false, (BLOCK == 256)>(a, i, e);
-    const float4 action = reinterpret_cast<const float4*>(actions)[i];
+    if constexpr (DEFER) {
+      load_env_ref(a, i, e);
+    } else {
+      load_env<LOAD, false, false>(a, i, e);
+      action = reinterpret_cast<const float4*>(actions)[i];
+    }
 #ifdef QD_STAMPS
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     QD_STAMP(1);
@@ -624,6 +687,23 @@ __global__ __launch_bounds__(BLOCK, (BLOCK == 256 && !spec_runtime<SPEC>() ? 2 :
   QD_STAMP(7);
   if ((threadIdx.x & 63) == 0 && blockIdx.x < 64) qd_rstamps[blockIdx.x * 2 + 1] = __builtin_amdgcn_s_memrealtime();
 #endif
+}
+
+// 64-thread workgroups (one wavefront per SIMD while the batch fits the chip once)
+template <bool LOAD, int BLOCK, int SPEC>
+__global__ __launch_bounds__(BLOCK, 1) void k_step(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+                                                   float* __restrict__ reward, uint8_t* __restrict__ trunc) {
+  static_assert(BLOCK == 64, "k_step: 64-thread launches; 256-thread launches are k_step_wide");
+  step_body<LOAD, BLOCK, SPEC, false>(a.g, actions, a.npad, a.n, a.main_blocks, a, obs, reward, trunc);
+}
+// 256-thread workgroups, two wavefronts per SIMD (see above), arguments as in StepKernarg
+template <bool LOAD, int BLOCK, int SPEC>
+__global__ __launch_bounds__(BLOCK, (!spec_runtime<SPEC>() ? 2 : 1)) void k_step_wide(float4* g_pre, const float* __restrict__ actions, int npad_pre,
+                                                                                    int n_pre, int main_blocks_pre, KArgs a_in,
+                                                                                    float* __restrict__ obs, float* __restrict__ reward,
+                                                                                    uint8_t* __restrict__ trunc) {
+  static_assert(BLOCK == 256, "k_step_wide: 256-thread launches");
+  step_body<LOAD, BLOCK, SPEC, true>(g_pre, actions, npad_pre, n_pre, main_blocks_pre, a_in, obs, reward, trunc);
 }
 
 // ---- cooperative step: THREE wavefronts per 64 envs ------------------------------------------------------------
@@ -702,33 +782,35 @@ __device__ __forceinline__ void coop_obs_part(const KArgs& a, int i, int lane, c
 }
 
 template <int SPEC>
-__global__ __launch_bounds__(COOP_THREADS) void k_step_coop(KArgs a, const float* __restrict__ actions, float* __restrict__ obs,
+__global__ __launch_bounds__(COOP_THREADS) void k_step_coop(float4* g_pre, const float* __restrict__ actions, int npad_pre, int n_pre,
+                                                            int main_blocks_pre, KArgs a_in, float* __restrict__ obs,
                                                             float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
-  // train_PPO.py / train_RMA.py's configuration only.  train_LSTM.py's (SPEC_LSTM: the row carries the accelerometer, the reward
-  // is the 150-instruction pendulum-energy one) was built too and lost to the single-wave kernel once the reset pool delivered
-  // the sensor's affine form (6.46 against 5.41 us per step at 8192 envs): its extra work all lands on wave A's serial phases.
+  // arguments: see step_kargs
   static_assert(SPEC == SPEC_RMA, "cooperative step: LocalFrameRPYParamsEnv + distance_energy_reward on the load model");
   constexpr int D = spec_obs_dim<SPEC>();
   constexpr int KIND = SPEC == SPEC_RMA ? (int)OBS_RPY_PARAMS : (int)OBS_FULLSTATE;
   __shared__ CoopLds L;
-  if ((int)blockIdx.x >= a.main_blocks) {  // sampler workgroup (see "reset pool")
-    sampler_wave<true>(a, ((int)blockIdx.x - a.main_blocks) * COOP_THREADS + threadIdx.x);
+  if ((int)blockIdx.x >= main_blocks_pre) {  // sampler workgroup (see "reset pool")
+    const KArgs a = step_kargs(g_pre, npad_pre, n_pre, main_blocks_pre);
+    sampler_wave<true>(a, ((int)blockIdx.x - main_blocks_pre) * COOP_THREADS + threadIdx.x);
     return;
   }
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int i = blockIdx.x * 64 + lane;
-  const bool live = i < a.n;
+  const bool live = i < n_pre;
   QD_CSTAMP(0);
   // every wave fetches all of its env's planes, not just the ones its role reads: fetching per role, in order of need, was
   // measured 6 % SLOWER (4.48 against 4.22 us per step, same box, alternating runs) although it moves a third fewer bytes;
   // non-live lanes only keep the barriers company
+  // (they fetch the last env's planes: an unconditional fetch keeps the loads, the argument fetch and the first arithmetic in
+  // one basic block, in that order)
   EnvRegs e;
-  float4 action = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (live) {
-    load_env<true, false, false>(a, i, e);
-    action = reinterpret_cast<const float4*>(actions)[i];
-  }
+  const int il = live ? i : n_pre - 1;
+  load_env_planes<true, false, false>(g_pre, npad_pre, il, e);
+  const float4 action = reinterpret_cast<const float4*>(actions)[il];
+  const KArgs a = step_kargs(g_pre, npad_pre, n_pre, main_blocks_pre);
+  if (live) load_env_ref(a, i, e);
   Factor<double> f;
 #ifdef QD_STAMPS
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1745,26 +1827,33 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   // one wavefront per workgroup while the batch fits the chip once (1024 SIMDs x 64 lanes = 65536 envs: every wave
   // has a SIMD to itself); 256-thread workgroups capped at 256 registers beyond that (two waves per SIMD)
-#define QD_STEP_LAUNCH(LOADV, BLK, SPECV)                                                                         \
+#define QD_STEP_LAUNCH_64(LOADV, SPECV)                                                                            \
   do {                                                                                                            \
     KArgs kk = k;                                                                                                 \
-    kk.main_blocks = (k.n + BLK - 1) / BLK;                                                                       \
-    QD_LAUNCH((k_step<LOADV, BLK, SPECV>), dim3(kk.main_blocks * ((k.use_pool && BLK == 64) ? 2 : 1)), dim3(BLK), 0, S(stream), kk, \
-              actions, obs, reward, truncated);                                                                   \
+    kk.main_blocks = blocks64(k.n);                                                                               \
+    QD_LAUNCH((k_step<LOADV, 64, SPECV>), dim3(kk.main_blocks * (k.use_pool ? 2 : 1)), dim3(64), 0, S(stream), kk, actions, obs, \
+              reward, truncated);                                                                                 \
   } while (0)
-#define QD_STEP_BLOCK(BLK)                                                   \
+#define QD_STEP_LAUNCH_256(LOADV, SPECV)                                                                           \
+  do {                                                                                                            \
+    KArgs kk = k;                                                                                                 \
+    kk.main_blocks = (k.n + 255) / 256;                                                                           \
+    QD_LAUNCH((k_step_wide<LOADV, 256, SPECV>), dim3(kk.main_blocks), dim3(256), 0, S(stream), kk.g, actions, kk.npad, kk.n,     \
+              kk.main_blocks, kk, obs, reward, truncated);                                                        \
+  } while (0)
+#define QD_STEP_BLOCK(L)                                                     \
   do {                                                                       \
     if (env->load) {                                                         \
-      if (env->spec == SPEC_RMA) QD_STEP_LAUNCH(true, BLK, SPEC_RMA);        \
-      else if (env->spec == SPEC_LSTM) QD_STEP_LAUNCH(true, BLK, SPEC_LSTM); \
-      else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC_FS1); \
-      else if (env->spec == SPEC_FLOOR) QD_STEP_LAUNCH(true, BLK, SPEC_FLOOR); \
-      else QD_STEP_LAUNCH(true, BLK, SPEC_GENERIC);                          \
+      if (env->spec == SPEC_RMA) L(true, SPEC_RMA);                          \
+      else if (env->spec == SPEC_LSTM) L(true, SPEC_LSTM);                   \
+      else if (env->spec == SPEC_GENERIC_FS1) L(true, SPEC_GENERIC_FS1);     \
+      else if (env->spec == SPEC_FLOOR) L(true, SPEC_FLOOR);                 \
+      else L(true, SPEC_GENERIC);                                            \
     } else {                                                                 \
-      if (env->spec == SPEC_SIMPLE) QD_STEP_LAUNCH(false, BLK, SPEC_SIMPLE); \
-      else if (env->spec == SPEC_GENERIC_FS1) QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC_FS1); \
-      else if (env->spec == SPEC_FLOOR) QD_STEP_LAUNCH(false, BLK, SPEC_FLOOR); \
-      else QD_STEP_LAUNCH(false, BLK, SPEC_GENERIC);                         \
+      if (env->spec == SPEC_SIMPLE) L(false, SPEC_SIMPLE);                   \
+      else if (env->spec == SPEC_GENERIC_FS1) L(false, SPEC_GENERIC_FS1);    \
+      else if (env->spec == SPEC_FLOOR) L(false, SPEC_FLOOR);                \
+      else L(false, SPEC_GENERIC);                                           \
     }                                                                        \
   } while (0)
   if (env->load && env->spec == SPEC_RMA && k.n <= qd_coop_max_envs()) {
@@ -1772,11 +1861,13 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
     KArgs kk = k;
     kk.main_blocks = blocks64(k.n);
     const dim3 grid(kk.main_blocks + (k.use_pool ? (k.n + COOP_THREADS - 1) / COOP_THREADS : 0));
-    QD_LAUNCH((k_step_coop<SPEC_RMA>), grid, dim3(COOP_THREADS), 0, S(stream), kk, actions, obs, reward, truncated);
-  } else if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(256);
-  else QD_STEP_BLOCK(64);
+    QD_LAUNCH((k_step_coop<SPEC_RMA>), grid, dim3(COOP_THREADS), 0, S(stream), kk.g, actions, kk.npad, kk.n, kk.main_blocks, kk, obs, reward,
+              truncated);
+  } else if (k.n >= qd_block_threshold()) QD_STEP_BLOCK(QD_STEP_LAUNCH_256);
+  else QD_STEP_BLOCK(QD_STEP_LAUNCH_64);
 #undef QD_STEP_BLOCK
-#undef QD_STEP_LAUNCH
+#undef QD_STEP_LAUNCH_64
+#undef QD_STEP_LAUNCH_256
   QD_LAUNCH_CHECK();
   return QD_OK;
 }

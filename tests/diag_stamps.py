@@ -1,6 +1,6 @@
 """Diagnostic (not a test): per-phase cycle shares of the step kernel from a -DQD_STAMPS build.
 usage: QD_LIB=tests/_build/libqd_diag.so [QD_DIAG_CONFIG=config5 QD_DIAG_ENVS=8192] python tests/diag_stamps.py
-(build: hipcc -O3 -std=c++17 --offload-arch=gfx950 -shared -fPIC -fno-gpu-rdc -DQD_STAMPS -o tests/_build/libqd_diag.so mujoco-drone_amd/csrc/qd_kernels.hip)"""
+(build: python mujoco-drone_amd/build.py --variant diag -DQD_STAMPS)"""
 import ctypes as C
 import os
 import sys
