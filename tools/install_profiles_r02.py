@@ -41,8 +41,10 @@ p["detail"] = {"4096": {"fetch_bytes": f4, "write_bytes": w4, "per_env_step": (f
                "1048576": {"fetch_bytes": f1, "write_bytes": w1, "per_env_step": (f1 + w1) / 1048576, "kernel": S["r02_pmc_n1m"]["step_kernel_trace"]["kernel"]}}
 json.dump(p, open(os.path.join(dst, "pmc_traffic.json"), "w"), indent=1)
 print("traffic per env-step:", {k: round(v["per_env_step"], 1) for k, v in p["detail"].items()})
-for f in ("r02_bench_default.json", "r02_bench_steps20.json", "r02_coop_vs_singlewave.txt", "r02_coop_timeline.txt", "r02_env_count_sweep.txt"):
-    shutil.copy(os.path.join(ev, f), os.path.join(dst, f))
+for f in ("r02_bench_default.json", "r02_bench_steps20.json", "r02_coop_vs_singlewave.txt", "r02_coop_timeline.txt", "r02_env_count_sweep.txt",
+          "r02_fragment_length.txt", "r02_kernel_start_latency.txt"):
+    if os.path.exists(os.path.join(ev, f)):
+        shutil.copy(os.path.join(ev, f), os.path.join(dst, f))
 for f in ("r02_bench_default.json", "r02_bench_steps20.json"):
     d = json.loads(open(os.path.join(dst, f)).read())
     r = d["roofline"]

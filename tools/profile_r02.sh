@@ -28,7 +28,7 @@ pmc1m)
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/m0 -- python3 bench.py $A $B > /dev/null
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/mf -- python3 bench.py $A $B > /dev/null
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/mw -- python3 bench.py $A $B > /dev/null
-  python3 profiles/summarize.py r02_pmc_n1m $RAW/m0 --kernel "k_step<" --out $OUT --pmc fetch=$RAW/mf --pmc write=$RAW/mw
+  python3 profiles/summarize.py r02_pmc_n1m $RAW/m0 --kernel "k_step_wide<" --out $OUT --pmc fetch=$RAW/mf --pmc write=$RAW/mw
   ;;
 sq)
   export QD_GRAPH_MIN_STEPS=2000000000 QD_BENCH_RAMP_STEPS=1024
