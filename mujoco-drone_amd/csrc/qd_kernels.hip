@@ -87,12 +87,15 @@ struct EnvRegs {  // everything one lane keeps in registers for one env
 constexpr uint32_t FLAG_ACC_STALE = 1u;
 
 // one lane asks for a refill of its env's reset-pool entries (see "reset pool"; the counter covers the lane's 64-env group)
+// (the counters are addressed as GLOBAL memory explicitly: a KArgs rebuilt from dwords -- step_kargs -- has lost the address space
+// of its pointers, and a FLAT atomic also counts on the LDS counter, so the next workgroup barrier would wait for it)
+typedef __attribute__((address_space(1))) uint32_t* need_ptr;
 __device__ __forceinline__ void pool_request(const KArgs& a, int i) {
-  __hip_atomic_fetch_add(a.need + (i >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add((need_ptr)a.need + (i >> 6), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 // bookkeeping of how in-kernel resets got their state (a handful of atomics per launch: only truncating lanes come here)
 __device__ __forceinline__ void pool_count(const KArgs& a, bool taken) {
-  __hip_atomic_fetch_add(a.need + (a.npad >> 6) + (taken ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_fetch_add((need_ptr)a.need + (a.npad >> 6) + (taken ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Compile-time specialisations of the fused step for the configurations the reference trains with; every other
@@ -358,7 +361,7 @@ template <bool LOAD>
 __device__ __forceinline__ void sampler_wave(const KArgs& a, int j) {
   const int w = j >> 6;
   if ((w << 6) >= a.n) return;
-  const uint32_t pending = __hip_atomic_load(a.need + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t pending = __hip_atomic_load((need_ptr)a.need + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (pending == 0u) return;
   bool done = true;
   if (j < a.n) {
@@ -369,7 +372,7 @@ __device__ __forceinline__ void sampler_wave(const KArgs& a, int j) {
     done = pool_fill<LOAD>(a, j, next, (next & 1u) ? ty : tx);
   }
   // entries that still lack a stage keep the request alive: the next launch's sampler comes back for them
-  if (__all(done ? 1 : 0) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_sub(a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__all(done ? 1 : 0) && (threadIdx.x & 63) == 0) __hip_atomic_fetch_sub((need_ptr)a.need + w, pending, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // what a reset does to everything but the sampled state (shared by the single-wave and the cooperative step)
@@ -862,6 +865,15 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(float4* g_pre, const
       for (int k = 0; k < 5; k++) L.nxt[k][lane] = nx[k];
     }
   }
+  // EVERY plane waited for before the first barrier, whether the wave's role read it or not.  Left to itself the compiler
+  // waits plane by plane as values are needed and never for the planes a role does not read -- until the wave reuses one of
+  // their registers, by which time (phase 3) the state stores are in flight, and the only way to wait for that old load is
+  // to wait for the stores behind it too (s_waitcnt vmcnt(3) in the middle of the observation arithmetic: 4.30 us per step
+  // against 4.00).  (Until this was understood the kernel owed the same effect to an accident: FLAT atomics on the refill
+  // counters put the compiler's wait insertion into its conservative mode, one vmcnt(0) at the top -- 4.02 us.)
+  asm volatile("" ::"v"(e.s.px), "v"(e.s.qw), "v"(e.s.vx), "v"(e.s.wx), "v"(e.s.a0), "v"(e.s.thd2), "v"(e.M.m0), "v"(e.M.I0z),
+               "v"(e.M.inv_tau), "v"(e.M.klin0), "v"(e.M.qly0), "v"(e.M.qaz0), "v"(e.M.qla2), "v"(e.par[0]), "v"(e.par[4]),
+               "v"(action.x));
   QD_CSTAMP(2);
   coop_barrier();
   QD_CSTAMP(3);
@@ -974,7 +986,14 @@ __global__ __launch_bounds__(COOP_THREADS) void k_step_coop(float4* g_pre, const
     const int total = rows * D, n4 = total >> 2;
     const float4* t4 = reinterpret_cast<const float4*>(L.tile);
     float4* d4 = reinterpret_cast<float4*>(obs + (size_t)base_env * D);
-    for (int j = threadIdx.x; j < n4; j += COOP_THREADS) store_streaming(d4 + j, t4[j]);
+    // two rounds cover the tile (64 rows x <= 24 floats = 384 chunks = 2 x 192 threads): both LDS reads in flight before the
+    // first store, no loop around one read-wait-store at a time
+    static_assert(sizeof(L.tile) / 16 <= 2 * COOP_THREADS, "flush: two rounds of 16-byte chunks");
+    const int j0 = threadIdx.x, j1 = threadIdx.x + COOP_THREADS;
+    const float4 c0 = t4[j0], c1 = t4[j1];   // inside the tile whatever n4 is; only the stores are conditional
+    asm volatile("" ::"v"(c0.x), "v"(c1.x));  // (both reads ahead of the first branch: the compiler sinks them into the branches)
+    if (j0 < n4) store_streaming(d4 + j0, c0);
+    if (j1 < n4) store_streaming(d4 + j1, c1);
     for (int j = (n4 << 2) + threadIdx.x; j < total; j += COOP_THREADS) __builtin_nontemporal_store(L.tile[j], obs + (size_t)base_env * D + j);
   }
   QD_CSTAMP(8);
