@@ -93,3 +93,25 @@ def test_bench_single_rank_dry_line():
     assert p.returncode == 0, p.stderr[-2000:]
     out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert out["n_gpus"] == 1 and out["config"]["trajectory_all_gather"] is None and out["dry_run"] is True
+
+
+def test_step_kernel_codegen_facts(bld):
+    """Properties of the step kernels' machine code that are worth 0.2-0.3 us each of the 4 us step ("The start
+    of the kernel", "Where the waits go") and that a compiler or source change can silently undo: the first loads leave on
+    preloaded SGPRs, no FLAT access (a FLAT atomic counts on the LDS counter, and its mere presence changes where the compiler
+    waits), three barriers, and NO wait for a global load once the first barrier is passed (it would wait for the state stores)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("kernel_isa_check", os.path.join(ROOT, "tools", "kernel_isa_check.py"))
+    chk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(chk)
+    coop = chk.kernel_facts("k_step_coop<1>")
+    assert coop["kernarg_preload_dwords"] == 7, coop          # g (2), actions (2), npad, n, main_blocks
+    assert coop["flat_memory_instructions"] == 0, coop
+    assert coop["barriers"] == 3, coop
+    assert coop["vmcnt_waits_after_first_barrier"] == 0, coop
+    assert coop["global_atomics"] == 3, coop                  # pool_request, pool_count (main path), the sampler's counter update
+    wide = chk.kernel_facts("k_step_wide<true, 256, 1>")
+    assert wide["kernarg_preload_dwords"] == 7 and wide["flat_memory_instructions"] == 0, wide
+    for pat in ("k_step<true, 64, 1>", "k_step<true, 64, 2>", "k_step<false, 64, 3>"):
+        k = chk.kernel_facts(pat)
+        assert k["kernarg_preload_dwords"] == 0 and k["flat_memory_instructions"] == 0, k   # struct-first signature, global accesses
