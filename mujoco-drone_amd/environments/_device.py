@@ -151,7 +151,8 @@ class DeviceEnv:
             raise ValueError("Action dimension mismatch")
         if tuple(obs.shape) != (T, self.n, self.D) or tuple(reward.shape) != (T, self.n) or tuple(truncated.shape) != (T, self.n):
             raise ValueError("fragment buffers must be [T,N,D], [T,N], [T,N]")
-        L.check(self.lib.qd_step_fragment(self.handle, _ptr(actions), T, _ptr(obs), _ptr(reward), _ptr(truncated), self._stream()))
+        L.check(self.lib.qd_step_fragment(self.handle, actions.data_ptr(), T, obs.data_ptr(), reward.data_ptr(), truncated.data_ptr(),
+                                          _raw_stream(self._dev_index)))
         return obs, reward, truncated
 
     def pool_counters(self):
