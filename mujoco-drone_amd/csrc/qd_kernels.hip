@@ -1560,10 +1560,18 @@ static int qd_graph_min_steps() {
   static const int v = [] { const char* e = getenv("QD_GRAPH_MIN_STEPS"); return e ? atoi(e) : 128; }();
   return v;
 }
-// largest batch stepped by the three-wave cooperative kernel (3 waves per 64 envs must find idle SIMDs: 16384 envs = 768
-// waves on 1024 SIMDs); QD_COOP_MAX_ENVS overrides it (0 switches the kernel off)
+// largest batch stepped by the three-wave cooperative kernel (3 waves per 64 envs must find idle SIMDs; measured against the
+// single-wave kernel: 5.13 / 5.40 us at 16384 envs, 5.95 / 6.25 at 24576, 10.1 / 7.1 at 32768); QD_COOP_MAX_ENVS overrides it
+// (0 switches the kernel off)
 static int qd_coop_max_envs() {
-  static const int v = [] { const char* e = getenv("QD_COOP_MAX_ENVS"); return e ? atoi(e) : 16384; }();
+  static const int v = [] { const char* e = getenv("QD_COOP_MAX_ENVS"); return e ? atoi(e) : 24576; }();
+  return v;
+}
+// batches below this size run reset-pool sampler workgroups next to the stepping ones (as many again for the 64-thread kernels:
+// from 32768 envs the two together no longer find a SIMD each -- 49152 envs: 10.8 us per step with samplers, 7.4 with the
+// resets sampled in the stepping waves; 16384: 5.4 against 6.1); QD_POOL_MAX_ENVS overrides it
+static int qd_pool_max_envs() {
+  static const int v = [] { const char* e = getenv("QD_POOL_MAX_ENVS"); return e ? atoi(e) : 32768; }();
   return v;
 }
 static inline hipStream_t S(void* s) { return reinterpret_cast<hipStream_t>(s); }
@@ -1655,7 +1663,7 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.frame_skip = c->frame_skip; k.ctrl_map = c->ctrl_map; k.obs_kind = c->obs_kind; k.reward_kind = c->reward_kind;
   k.term_kind = c->term_kind; k.max_distance = (float)c->max_distance; k.max_steps = c->max_steps;
   k.auto_reset = c->auto_reset; k.D = e->D; k.seed = c->seed;
-  // sampler workgroups pay off while the launch is a latency chain (few waves, idle CUs); with >= 65536 envs the
+  // sampler workgroups pay off while the launch is a latency chain (few waves, idle CUs); with >= 32768 envs the
   // chip is full and a second set of workgroups only adds traffic, so truncated lanes sample inline there
   if (c->ref_mode < QD_REF_STATIC || c->ref_mode > QD_REF_RAMP) { delete e; return fail(QD_ERR_INVALID, "unknown ref_mode %d", c->ref_mode); }
   k.ref_k0 = 0; k.ref_kmax = 0; k.ref_dt = k.ref_t0 = k.ref_inv_span = 0.f;
@@ -1680,7 +1688,7 @@ int qd_create(const qd_config* c, void* arena, size_t arena_bytes, qd_env** out)
   k.ref_radius = (float)c->ref_radius;
   k.ref_omega_dt = (float)(6.283185307179586 * c->ref_frequency * c->timestep * c->frame_skip);
   k.ref_phase_step = (float)(6.283185307179586 / c->num_envs);
-  k.use_pool = (c->auto_reset && c->random_start != QD_START_FIXED && c->num_envs < 65536) ? 1 : 0;
+  k.use_pool = (c->auto_reset && c->random_start != QD_START_FIXED && c->num_envs < qd_pool_max_envs()) ? 1 : 0;
   k.main_blocks = 0;
   {
     const int ok = c->obs_kind;

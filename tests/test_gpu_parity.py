@@ -1019,17 +1019,17 @@ def test_step_fragment_policies_long_and_short_runs(qd):
                 assert torch.equal(tr[t], trn)
 
 
-@pytest.mark.parametrize("n", [1, 63, 65, 4097, 16384, 16385, 65535, 65536, 98303, 98304, 131073])
+@pytest.mark.parametrize("n", [1, 63, 65, 4097, 24576, 24577, 32767, 32768, 65535, 65536, 98303, 98304, 131073])
 def test_ragged_and_threshold_batch_sizes(qd, n):
     """batch sizes that are not multiples of the wavefront / workgroup, and the sizes at which the library switches launch
-    variants (three-wave cooperative kernel up to 16384 envs, one wave per 64 envs above, reset-sampler workgroups below 65536
+    variants (three-wave cooperative kernel up to 24576 envs, one wave per 64 envs above, reset-sampler workgroups below 32768
     envs, 256-thread workgroups from 98304): env i's observations, rewards and truncations, through resets and re-sampling, are
-    bit-identical to the same env in a smaller batch of the SAME launch variant (64 envs for the cooperative kernel, 16385 for
+    bit-identical to the same env in a smaller batch of the SAME launch variant (64 envs for the cooperative kernel, 24577 for
     the 64-thread one).  Variants are compiled separately and their fused multiply-adds fall differently, 1 ulp per step
     (tests/diag_variant_diff.py), so from 98304 envs the comparison is to a 64-env batch at 2e-5 (ten float32 ulps of the 15 m altitude) over a 7-step episode; the
     last env of the ragged tail is finite and stepped exactly as often as the first"""
     L, T = qd._lib, 24
-    m = min(n, 64) if (n <= 16384 or n >= 98304) else 16385
+    m = min(n, 64) if (n <= 24576 or n >= 98304) else 24577
     mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, start=1, random_params=1, auto_reset=1, max_steps=7, seed=9))
     big, small = mk(n), mk(m)
     big.reset(); small.reset()
