@@ -174,7 +174,12 @@ int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* senso
  * ctrl map, frame_skip x mj_step, num_steps += 1, truncation, reward, observation.
  * n_action_values must equal 4*num_envs, else QD_ERR_SHAPE.  actions[N,4], obs[N,D],
  * reward[N], truncated[N] (uint8).  With auto_reset, truncated envs are re-sampled in the same
- * launch and their obs row is the first observation of the new episode. */
+ * launch and their obs row is the first observation of the new episode.
+ * Launch variants are chosen by batch size (results per env do not depend on the variant beyond float32 rounding, and not
+ * at all within one): the three-wavefront cooperative kernel for train_PPO.py / train_RMA.py's configuration up to 24576
+ * envs (environment variable QD_COOP_MAX_ENVS, 0 = never), one wavefront per 64 envs up to 98303, 256-thread workgroups
+ * above (QD_BLOCK_THRESHOLD); reset-pool sampler workgroups ride along below 32768 envs (QD_POOL_MAX_ENVS).  The variables
+ * are read once per process and exist for measurements. */
 int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
             uint8_t* truncated, void* stream);
 /* T consecutive qd_step launches (same kernels, same results: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N])
