@@ -467,7 +467,7 @@ __device__ __forceinline__ void write_obs_row(const KArgs& a, const EnvRegs& e, 
 // acknowledgements at the end of every launch (5.32 -> 4.89 us per step on 1024-step fragments, 4.75 -> 4.65 on 128-step ones).
 __device__ __forceinline__ void store_streaming(float4* p, float4 v) {
   typedef float nt_f4 __attribute__((ext_vector_type(4)));
-  __builtin_nontemporal_store(nt_f4{v.x, v.y, v.z, v.w}, reinterpret_cast<nt_f4*>(p));
+  __builtin_nontemporal_store((nt_f4{v.x, v.y, v.z, v.w}), reinterpret_cast<nt_f4*>(p));
 }
 __device__ __forceinline__ void flush_obs(const float* tile, float* dst, int rows, int D) {
   const int lane = threadIdx.x & 63;
