@@ -29,6 +29,7 @@ stepping (the fragments are filled with a rank pattern); the line says "dry_run"
 import argparse
 import json
 import os
+import re
 import socket
 import subprocess
 import sys
@@ -494,6 +495,17 @@ def main():
                 prof_us = json.load(open(prof))["step_kernel_trace"]["avg_ns"] * 1e-3
             except Exception:
                 prof_us = None
+        # ... and the profiler's own share, calibrated on a kernel that does nothing (tools/profile_r02.sh calib,
+        # profiles/r02_profiler_calibration.txt): rocprofv3's average dispatch duration of a near-empty kernel in a replayed graph
+        # minus that graph's live period per launch without the profiler
+        prof_over = None
+        try:
+            cal = open(os.path.join(ROOT, "profiles", "r02_profiler_calibration.txt")).read()
+            live = [float(x) for x in re.findall(r"launches: ([0-9.]+) us per launch", cal.split("== the same script")[0])]
+            avg = float(re.search(r"average duration ([0-9.]+) ns", cal).group(1)) * 1e-3
+            prof_over = avg - min(live)
+        except Exception:
+            prof_over = None
         copy_gbps = measured_copy_gbps(device)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
@@ -502,6 +514,7 @@ def main():
                                                "1024-step fragments), independent of --steps" % klaunches,
                            "timed_region_us_per_step": kus_timed, "isolated_launch_us": iso_us,
                            "rocprofv3_avg_kernel_us": prof_us,
+                           "rocprofv3_empty_kernel_excess_us": prof_over,
                            "frac_at_rocprofv3_duration": (bytes_per_launch / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof_us else None,
                            "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
                            "env_steps_per_launch": n, "measured_copy_GBps": copy_gbps,

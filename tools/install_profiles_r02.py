@@ -29,6 +29,11 @@ for f in ("bench_s20_profiled.json", "bench_default_profiled.json"):
     shutil.copy(os.path.join(src, f), os.path.join(dst, "r02_" + f))
 
 
+for f in ("r02_profiler_calibration.txt", "r02_calib_empty_rocprof_summary.json"):
+    if os.path.exists(os.path.join(src, f)):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+
+
 def traffic(d):
     return (d["pmc"]["fetch"]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2,      # KiB, doubled per the gfx950 calibration
             d["pmc"]["write"]["WRITE_SIZE"]["mean_per_dispatch"] * 1024)

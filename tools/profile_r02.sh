@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 profile collection on the GPU box (run through gpurun from the repository root); summaries land in gpurun_out/prof_r02/.
-# usage: tools/profile_r02.sh <part>   with part = trace | pmc4096 | pmc1m | sq
+# usage: tools/profile_r02.sh <part>   with part = trace | pmc4096 | pmc1m | sq | calib
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r02; RAW=/tmp/prof_raw; mkdir -p $OUT $RAW
@@ -40,6 +40,16 @@ sq)
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/q2 -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $RAW/q3 -- python3 bench.py --steps 1024 --warmup 64 $B > /dev/null
   python3 profiles/summarize.py r02_sq_singlewave_n4096 $RAW/q2 --kernel "k_step<" --out $OUT --pmc sq=$RAW/q3
+  ;;
+calib)
+  # what rocprofv3 itself adds: a replayed graph of 512 dependent launches of a near-empty kernel, live period printed by the
+  # script while it is being profiled, next to the dispatch duration the profiler reports for the same launches
+  python3 tests/diag_profiler_calib.py 2>&1 | grep "us per launch" > $OUT/calib_unprofiled.txt
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/cal -- python3 tests/diag_profiler_calib.py 2>&1 | grep "us per launch" > $OUT/calib_profiled.txt
+  python3 profiles/summarize.py r02_calib_empty $RAW/cal --kernel k_pid_reset --out $OUT
+  { echo "== un-profiled"; cat $OUT/calib_unprofiled.txt; echo "== the same script under rocprofv3 --kernel-trace --stats"; cat $OUT/calib_profiled.txt;
+    echo "== rocprofv3's dispatch statistics of k_pid_reset in that run";
+    python3 -c "import json; t=json.load(open('$OUT/r02_calib_empty_rocprof_summary.json'))['step_kernel_trace']; print('dispatches %d  average duration %.0f ns  median %.0f ns  median start-to-start %.0f ns' % (t['dispatches'], t['avg_ns'], t['median_ns'], t['median_start_to_start_ns']))"; } > $OUT/r02_profiler_calibration.txt
   ;;
 esac
 ls -la $OUT
