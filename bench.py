@@ -522,7 +522,7 @@ def main():
                            "WRITE_SIZE passes of this command with direct launches, tools/profile_r02.sh; FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
                            "note": "4096 envs = 192 wavefronts (3 per 64 envs, k_step_coop) on 1024 SIMDs: the launch is a dependent "
                                    "instruction chain between two kernel boundaries, not HBM-bound (see DESIGN.md and the env-count "
-                                   "sweep in `extras`: 54-57 % of the roofline from 10^6 envs)"}
+                                   "sweep in `extras`: 55-59 % of the roofline from 10^6 envs)"}
         if not args.no_extras and world == 1:
             extras = {}
             try:
