@@ -45,14 +45,19 @@ struct SampleCfg {
 
 QD_HD float clipf(float x, float lim) { return x < -lim ? -lim : (x > lim ? lim : x); }
 
-// the 15 standard normals and 2 uniforms one reset consumes, in the reference's draw order
-QD_HD void sample_draws(uint64_t seed, uint32_t env, uint32_t episode, float z[16], float u[2]) {
+// the 15 standard normals and 2 uniforms one reset consumes, in the reference's draw order -- in two stages, because the
+// persistent fragment kernel (qd_rollout_coop.hip) spreads one sample over the idle slots of several steps:
+//   sample_words<B0, B1>  Philox blocks B0 .. B1-1 of the (env, episode) stream -> w[4 B0 .. 4 B1 - 1]   (~100 instructions per block)
+//   draws_from_words      Box-Muller pairs r = sqrt(-2 ln u1), angle = 2 pi u2 over w[0..15] -> z[16]; w[16], w[17] -> u[2]
+template <int B0, int B1>
+QD_HD void sample_words(uint64_t seed, uint32_t env, uint32_t episode, uint32_t* w /* [20] */) {
   const uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
-  uint32_t w[20];
 #pragma unroll
-  for (uint32_t b = 0; b < 5; b++) philox4x32_10(env, episode, b, STREAM_STATE, k0, k1, w + 4 * b);
+  for (uint32_t b = B0; b < B1; b++) philox4x32_10(env, episode, b, STREAM_STATE, k0, k1, w + 4 * b);
+}
+QD_HD void draws_from_words(const uint32_t w[20], float z[16], float u[2]) {
 #pragma unroll
-  for (int i = 0; i < 8; i++) {  // Box-Muller pairs: r = sqrt(-2 ln u1), angle = 2 pi u2
+  for (int i = 0; i < 8; i++) {
     const float u1 = u32_to_unit(w[2 * i]), u2 = u32_to_unit(w[2 * i + 1]);
 #if defined(__HIP_DEVICE_COMPILE__)
     // v_log_f32 is log2; v_sin_f32 / v_cos_f32 take their argument in revolutions, i.e. u2 itself
@@ -67,6 +72,11 @@ QD_HD void sample_draws(uint64_t seed, uint32_t env, uint32_t episode, float z[1
   }
   u[0] = u32_to_unit(w[16]);
   u[1] = u32_to_unit(w[17]);
+}
+QD_HD void sample_draws(uint64_t seed, uint32_t env, uint32_t episode, float z[16], float u[2]) {
+  uint32_t w[20];
+  sample_words<0, 5>(seed, env, episode, w);
+  draws_from_words(w, z, u);
 }
 
 // BaseDroneEnv.sample_state: raw draws -> qpos / qvel (activations are NOT touched: QUIRK C-2)

@@ -1,0 +1,407 @@
+// qd_rollout_coop.hip -- k_rollout_coop: a whole rollout fragment (T env steps) of the training configuration in ONE launch.
+//
+// Replaces, for T consecutive calls, BaseDroneEnv.vector_step (environments/BaseDroneEnv.py:259-294) as the sampler of
+// train_PPO.py / train_RMA.py drives it in 1024-step fragments (train_RMA.py:63): ctrl map, mj_step, counters, truncation,
+// reward, (auto-)reset, observation -- the load model with LocalFrameRPYParamsEnv + distance_energy_reward (SPEC_RMA).
+//
+// Why: one launch per step cannot go below the cost of a dependent launch (1.5 us empty, ~2.0 us with the step's loads and
+// stores, profiles/r02_microbench.txt) whatever the kernel does, which caps the 4096-env configuration below 10 % of the HBM
+// roofline.  Here a workgroup of FOUR wavefronts (the four SIMDs of one CU) owns 64 envs for all T steps; the state never
+// leaves the CU between steps, only actions come in and observation rows / rewards / flags go out (109 B per env-step instead
+// of the 309 B a per-step launch moves).  Lane l of every wave works on env l of the group; the waves exchange through LDS at
+// two workgroup barriers per step:
+//
+//   wave A (solver)     mass_factor(s_t), activation filter | reduce_rhs, finish_accel(implicit), integrate, truncation,
+//                                                            | in-kernel reset (pool entry from LDS) -> publishes s_{t+1}
+//   wave B (applied)    attitude, applied_wrench(s_t)        | -
+//   wave C (inertial)   inertial_wrench(s_t)                 | one CHUNK of the workgroup's own reset sampler (below)
+//   wave D (epilogue)   one step behind: observation row of s_t (= the row of step t-1) into its LDS tile | reward and flags
+//                       of step t-1, 16-byte streaming stores of the 64 rows
+//                     barrier 1 ^                                                                  barrier 2 ^
+//
+// The critical path of a step is {mass_factor | applied_wrench | inertial_wrench} -> solve + integrate; everything else (the
+// whole epilogue of k_step_coop's phase 3, the next action's fetch, the sampling of new initial states) runs beside it.
+// The arithmetic is k_step_coop's: the same functions of qd_dynamics.h / qd_obsrew.h on the same float32 / float64 values,
+// so a fragment equals T x qd_step of the cooperative per-step kernel (tests/test_gpu_parity.py).
+//
+// The reset sampler.  k_step_coop gets the initial state of an env's next episode from the reset pool in the arena, kept
+// filled by sampler workgroups of LATER launches.  Inside one launch there is no later launch, so the pool moves into LDS
+// (both slots of every env: the entry of its current episode counter c and of c + 1, loaded from the arena at the start,
+// written back at the end) and wave C refills it in the ~1800 cycles per step it would otherwise idle through: a sample
+// (5 Philox blocks, 8 Box-Muller pairs, the transforms of sample_state: ~1000 instructions) is cut into three chunks, one
+// per step, for all lanes of the group that miss an entry when the job starts; the finished entries are committed at the
+// start of a phase 1, when wave A does not read the pool.  A sample is a pure function of (seed, env, episode), so whoever
+// computes it and whenever, the result is the same: wave A only ever READS the pool, takes the entry tagged with its counter
+// if it is there and samples inline if not (slower, same result) -- the hand-over is the workgroup barrier, there is no
+// two-slot global protocol and no fence.  Counted like in the per-step kernels (qd_pool_counters).
+#include "qd_env_device.h"
+
+namespace qd {
+
+constexpr int RC_THREADS = 256;
+
+struct RcLds {
+  float4 app[5][64];      // B -> A: Applied (F, t1) (Tq, t2) and the attitude matrix
+  double2 ine[4][64];     // C -> A: Inertial (F, Tq, t1, t2)
+  float4 st[6][64];       // A -> B, C, D: the state at the start of the next step (after the in-kernel reset of a truncated lane):
+                          //   (pos, th1) (quat) (vel, th2) (angvel, thd1) (act) (thd2, -, -, -)
+  float4 pre[6][64];      // A -> D: the state after the step and BEFORE the reset, truncated lanes only (the reward is of this state)
+  uint4 info[64];         // A -> C, D: (bit 0 truncated | bit 1 reset), episode counter of s_{t+1}, num_steps after the step, -
+  float4 nxt[2][5][64];   // the reset pool: slot e & 1 = entry of episode e, planes as in the arena (tag plane last)
+  float tile[64 * 24];    // wave D: the group's observation rows, row-major like the global span
+};
+
+__device__ __forceinline__ void rc_put_state(float4 (*st)[64], int lane, const State<float>& s) {
+  st[0][lane] = make_float4(s.px, s.py, s.pz, s.th1);
+  st[1][lane] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  st[2][lane] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  st[3][lane] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  st[4][lane] = make_float4(s.a0, s.a1, s.a2, s.a3);
+  st[5][lane] = make_float4(s.thd2, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void rc_get_state(const float4 (*st)[64], int lane, State<float>& s) {
+  const float4 p = st[0][lane], q = st[1][lane], v = st[2][lane], w = st[3][lane], c = st[4][lane], x = st[5][lane];
+  s.px = p.x; s.py = p.y; s.pz = p.z; s.th1 = p.w;
+  s.qw = q.x; s.qx = q.y; s.qy = q.z; s.qz = q.w;
+  s.vx = v.x; s.vy = v.y; s.vz = v.z; s.th2 = v.w;
+  s.wx = w.x; s.wy = w.y; s.wz = w.z; s.thd1 = w.w;
+  s.a0 = c.x; s.a1 = c.y; s.a2 = c.z; s.a3 = c.w;
+  s.thd2 = x.x;
+}
+// the env's reference at episode step k (static: `base`, fetched once)
+__device__ __forceinline__ void rc_ref(const KArgs& a, int i, int k, const float base[4], float ref[4]) {
+  if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, k, ref);
+  else { ref[0] = base[0]; ref[1] = base[1]; ref[2] = base[2]; ref[3] = base[3]; }
+}
+// a pre-sampled initial state into one slot of the LDS pool, planes and tag as pool_store() writes them to the arena
+__device__ __forceinline__ void pool_put_lds(float4 (*slot)[64], int lane, uint32_t episode, const State<float>& s) {
+  slot[0][lane] = make_float4(s.px, s.py, s.pz, s.th1);
+  slot[1][lane] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  slot[2][lane] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  slot[3][lane] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  slot[4][lane] = make_float4(s.thd2, __uint_as_float(episode), __uint_as_float(POOL_STATE), 0.f);
+}
+__device__ __forceinline__ bool rc_entry_valid(float4 tagp, uint32_t episode) {
+  return __float_as_uint(tagp.z) != 0u && __float_as_uint(tagp.y) == episode;
+}
+
+#ifdef QD_STAMPS
+// diagnostic build: cycle stamps of one step in the middle of the fragment, 16 per (workgroup, wave)
+__device__ unsigned long long qd_rcstamps[64 * 4 * 16];
+#define RC_STAMP(k)                                                                                          \
+  do {                                                                                                       \
+    if (t == (T >> 1)) {                                                                                     \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      unsigned long long t_;                                                                                 \
+      asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");                             \
+      __builtin_amdgcn_sched_barrier(0);                                                                     \
+      if (lane == 0 && blockIdx.x < 64) qd_rcstamps[(blockIdx.x * 4 + role) * 16 + (k)] = t_;                \
+    }                                                                                                        \
+  } while (0)
+#else
+#define RC_STAMP(k)
+#endif
+
+template <int SPEC>
+__global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
+                                                             float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
+  static_assert(SPEC == SPEC_RMA, "persistent fragment kernel: LocalFrameRPYParamsEnv + distance_energy_reward on the load model");
+  constexpr int D = spec_obs_dim<SPEC>();
+  constexpr int KIND = (int)OBS_RPY_PARAMS;
+  __shared__ RcLds L;
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int base_env = blockIdx.x * 64;
+  const int i = base_env + lane;
+  const bool live = i < a.n;
+  const int il = live ? i : a.n - 1;   // lanes past the batch work on a copy of the last env (no stores, no atomics)
+  const int n = a.n;
+  const float4* actions4 = reinterpret_cast<const float4*>(actions);
+
+  // every wave fetches its env's planes (what a role does not read is dropped by the compiler); the reference once
+  EnvRegs e;
+  load_env_planes<true, false, false>(a.g, a.npad, il, e);
+  float ref0[4] = {a.ref[0], a.ref[1], a.ref[2], a.ref[3]};
+  if (a.ref_mode == QD_REF_STATIC && a.per_env_ref) {
+    const float4 r = a.g[G_REF * a.npad + il];
+    ref0[0] = r.x; ref0[1] = r.y; ref0[2] = r.z; ref0[3] = r.w;
+  }
+
+  if (role == 0) {
+    // ================================================================ wave A: factorisation, solve, integration, resets
+    float4 act_next = actions4[il];
+    rc_put_state(L.st, lane, e.s);
+    L.info[lane] = make_uint4(0u, e.episode, (uint32_t)e.num_steps, 0u);
+    coop_barrier();   // P
+    Factor<double> f;
+    Rhs<double> r;
+    M3<float> R;
+    V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
+    for (int t = 0; t < T; t++) {
+      RC_STAMP(0);
+      const float4 action = act_next;
+      if (t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
+      // ---------------------------------------------------------- phase 1
+      const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
+      f = mass_factor(e.M, tg, a.h);
+      {
+        const float c0 = qclamp(0.1f + 0.9f * action.x, 0.f, 1.f), c1 = qclamp(0.1f + 0.9f * action.y, 0.f, 1.f);
+        const float c2 = qclamp(0.1f + 0.9f * action.z, 0.f, 1.f), c3 = qclamp(0.1f + 0.9f * action.w, 0.f, 1.f);
+        integrate_act(e.M, e.s, c0, c1, c2, c3, a.h);
+      }
+      rc_ref(a, i, e.num_steps, ref0, e.ref);
+      RC_STAMP(1);
+      coop_barrier();   // 1
+      RC_STAMP(2);
+      // ---------------------------------------------------------- phase 2
+      {
+        Applied<float> ap;
+        {
+          const float4 x0 = L.app[0][lane], x1 = L.app[1][lane], x2 = L.app[2][lane], x3 = L.app[3][lane], x4 = L.app[4][lane];
+          ap.F = mk<float>(x0.x, x0.y, x0.z); ap.t1 = x0.w;
+          ap.Tq = mk<float>(x1.x, x1.y, x1.z); ap.t2 = x1.w;
+          R.m00 = x2.x; R.m01 = x2.y; R.m02 = x2.z; R.m10 = x2.w; R.m11 = x3.x; R.m12 = x3.y; R.m20 = x3.z; R.m21 = x3.w; R.m22 = x4.x;
+        }
+        Inertial<double> in;
+        {
+          const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
+          in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
+        }
+        r = reduce_rhs(f, ap, in);
+      }
+      Accel<float> im;
+      V3<double> a0im;
+      finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+      im.lin = mul(R, cvt<float>(a0im));
+      w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
+      integrate_motion<float, true>(e.s, im, a.h);
+      e.flags &= ~FLAG_ACC_STALE;
+      e.num_steps += 1;
+      const int steps_post = e.num_steps;
+      bool tr;
+      {  // default_termination_fcn on the position alone (the same test truncated() makes on the state vector)
+        const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+        tr = !(qsqrt(dx * dx + dy * dy + dz * dz) <= a.max_distance) || e.num_steps >= a.max_steps;
+      }
+      const bool rst = a.auto_reset && tr;
+      if (rst) {
+        rc_put_state(L.pre, lane, e.s);
+        State<float> ns;   // the new episode's state; the activations carry over (reset_bookkeeping)
+        bool taken = false;
+        if (a.use_pool) {
+          const int sl = (int)(e.episode & 1u);
+          const float4 nx4 = L.nxt[sl][4][lane];
+          taken = rc_entry_valid(nx4, e.episode);
+          if (taken) {
+            const float4 p = L.nxt[sl][0][lane], q = L.nxt[sl][1][lane], v = L.nxt[sl][2][lane], w = L.nxt[sl][3][lane];
+            ns.px = p.x; ns.py = p.y; ns.pz = p.z; ns.th1 = p.w;
+            ns.qw = q.x; ns.qx = q.y; ns.qy = q.z; ns.qz = q.w;
+            ns.vx = v.x; ns.vy = v.y; ns.vz = v.z; ns.th2 = v.w;
+            ns.wx = w.x; ns.wy = w.y; ns.wz = w.z; ns.thd1 = w.w;
+            ns.thd2 = nx4.x;
+          }
+        }
+        if (!taken) sample_episode<true>(a, i, e.episode, ns);
+        ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
+        e.s = ns;
+        reset_bookkeeping(e.s, e.episode, e.num_steps);
+        e.flags |= FLAG_ACC_STALE;   // the row does not carry the sensor: recomputed by the next step, or by a getter that runs first
+        if (a.use_pool && live) pool_count(a, taken);
+      }
+      rc_put_state(L.st, lane, e.s);
+      L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
+      RC_STAMP(3);
+      coop_barrier();   // 2
+      RC_STAMP(4);
+    }
+    // the fragment's last step leaves what a per-step launch leaves: the state, and the accelerometer reading of that step
+    // (quirk C-6: the reading of the state the step STARTED from), also where a reset marked it stale
+    if (live) {
+      Accel<float> ex;
+      V3<double> a0ex;
+      finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+      const float g = float(Const::gravity);
+      e.acc = accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                            mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+      store_env(a, i, e);
+    }
+  } else if (role == 1) {
+    // ================================================================ wave B: thrust + drag on the three bodies
+    coop_barrier();   // P
+    for (int t = 0; t < T; t++) {
+      RC_STAMP(0);
+      State<float> s;
+      rc_get_state(L.st, lane, s);
+      const Tether<float> tg = tether_geometry(s.th1, s.th2);
+      const Att<float> at = attitude(s);
+      const Applied<float> ap = applied_wrench(e.M, s, at, tg);
+      L.app[0][lane] = make_float4(ap.F.x, ap.F.y, ap.F.z, ap.t1);
+      L.app[1][lane] = make_float4(ap.Tq.x, ap.Tq.y, ap.Tq.z, ap.t2);
+      L.app[2][lane] = make_float4(at.R.m00, at.R.m01, at.R.m02, at.R.m10);
+      L.app[3][lane] = make_float4(at.R.m11, at.R.m12, at.R.m20, at.R.m21);
+      L.app[4][lane] = make_float4(at.R.m22, 0.f, 0.f, 0.f);
+      RC_STAMP(1);
+      coop_barrier();   // 1
+      RC_STAMP(2);
+      coop_barrier();   // 2
+      RC_STAMP(4);
+    }
+  } else if (role == 2) {
+    // ================================================================ wave C: gravity + velocity products; the reset sampler
+    const bool pool = a.use_pool != 0 && a.auto_reset != 0;
+    {
+#pragma unroll
+      for (int k = 0; k < 5; k++) {
+        L.nxt[0][k][lane] = pool ? a.g[(G_NX0 + k) * a.npad + il] : make_float4(0.f, 0.f, 0.f, 0.f);
+        L.nxt[1][k][lane] = pool ? a.g[(G_NY0 + k) * a.npad + il] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+    }
+    coop_barrier();   // P
+    // the sampler job: per lane the episode it samples (NONE: the lane is not part of the job), the Philox words so far, the
+    // finished state; `jphase` is wave-uniform: 0 idle, 1..3 the chunk to run next, 4 finished -> commit
+    constexpr uint32_t NONE = 0xFFFFFFFFu;
+    uint32_t jx = NONE, jw[20];
+#pragma unroll
+    for (int k = 0; k < 20; k++) jw[k] = 0u;
+    State<float> jns;
+    jns.px = jns.py = jns.pz = jns.qw = jns.qx = jns.qy = jns.qz = jns.th1 = jns.th2 = 0.f;
+    jns.vx = jns.vy = jns.vz = jns.wx = jns.wy = jns.wz = jns.thd1 = jns.thd2 = jns.a0 = jns.a1 = jns.a2 = jns.a3 = 0.f;
+    int jphase = 0;
+    for (int t = 0; t < T; t++) {
+      RC_STAMP(0);
+      if (jphase == 4) {   // commit: wave A is in its phase 1 and does not read the pool
+        if (jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
+        jphase = 0;
+      }
+      State<float> s;
+      rc_get_state(L.st, lane, s);
+      const uint32_t episode = L.info[lane].y;
+      const float4 tag0 = L.nxt[0][4][lane], tag1 = L.nxt[1][4][lane];
+      const Tether<float> tg = tether_geometry(s.th1, s.th2);
+      V3<float> gt, w;
+      gravity_body(s, &gt, &w);
+      const Inertial<double> in = inertial_wrench(e.M, s, gt, w, tg);
+      L.ine[0][lane] = make_double2(in.F.x, in.F.y);
+      L.ine[1][lane] = make_double2(in.F.z, in.Tq.x);
+      L.ine[2][lane] = make_double2(in.Tq.y, in.Tq.z);
+      L.ine[3][lane] = make_double2(in.t1, in.t2);
+      RC_STAMP(1);
+      coop_barrier();   // 1
+      RC_STAMP(2);
+      if (pool) {
+        if (jphase == 0) {
+          // what is missing: the entry of the env's current counter first (it would be sampled inline), else the one after it
+          const bool have_c = rc_entry_valid((episode & 1u) ? tag1 : tag0, episode);
+          const bool have_n = rc_entry_valid((episode & 1u) ? tag0 : tag1, episode + 1u);
+          jx = !have_c ? episode : (!have_n ? episode + 1u : NONE);
+          if (__any(jx != NONE ? 1 : 0)) jphase = 1;
+        }
+        if (jphase == 1) {
+          sample_words<0, 3>(a.seed, (uint32_t)i, jx, jw);
+          jphase = 2;
+        } else if (jphase == 2) {
+          sample_words<3, 5>(a.seed, (uint32_t)i, jx, jw);
+          jphase = 3;
+        } else if (jphase == 3) {
+          float z[16], u[2];
+          draws_from_words(jw, z, u);
+          sample_state<true>(a.sc, z, u, jns);
+          jphase = 4;
+        }
+      }
+      RC_STAMP(3);
+      coop_barrier();   // 2
+      RC_STAMP(4);
+    }
+    // hand the pool back to the arena as the per-step kernels expect it: the entry of every env's current counter and of the
+    // one after it, complete (what the chunked job had not finished is sampled here, once per fragment)
+    if (pool) {
+      if (jphase == 4 && jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
+      const uint32_t episode = L.info[lane].y;
+#pragma unroll 1
+      for (uint32_t d = 0; d < 2; d++) {
+        const uint32_t x = episode + d;
+        if (!rc_entry_valid(L.nxt[x & 1u][4][lane], x)) {
+          State<float> ns;
+          sample_episode<true>(a, i, x, ns);
+          pool_put_lds(L.nxt[x & 1u], lane, x, ns);
+        }
+      }
+      if (live) {
+#pragma unroll
+        for (int k = 0; k < 5; k++) {
+          a.g[(G_NX0 + k) * a.npad + i] = L.nxt[0][k][lane];
+          a.g[(G_NY0 + k) * a.npad + i] = L.nxt[1][k][lane];
+        }
+      }
+    }
+  } else {
+    // ================================================================ wave D: observation rows, rewards, flags -- one step behind
+    float4 act_prev = actions4[il];   // the action of step t - 1 when iteration t uses it
+    coop_barrier();   // P
+    for (int t = 0; t <= T; t++) {
+      RC_STAMP(0);
+      float sv[33];
+      M3<float> Rq;
+      float ref_t[4];
+      uint4 info = make_uint4(0u, 0u, 0u, 0u);
+      bool rst = false;
+      if (t >= 1) {
+        info = L.info[lane];
+        rst = (info.x & 2u) != 0u;
+        State<float> s;
+        rc_get_state(L.st, lane, s);
+        rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
+        float refo[4] = {ref_t[0], ref_t[1], ref_t[2], ref_t[3]};
+        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, refo);   // a new episode's first row
+        float o[QD_MAX_OBS];
+        drone_state<float, true>(s, mk<float>(0.f, 0.f, 0.f), refo, e.par, sv, &Rq);
+        observe<float, 33, KIND>(sv, refo, o, &Rq);
+        float* row = L.tile + lane * D;
+#pragma unroll
+        for (int k = 0; k < D; k++) row[k] = o[k];
+      }
+      RC_STAMP(1);
+      if (t < T) coop_barrier();   // 1
+      RC_STAMP(2);
+      if (t >= 1) {
+        const float act4[4] = {act_prev.x, act_prev.y, act_prev.z, act_prev.w};
+        float rw = reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
+        if (__any(rst ? 1 : 0)) {   // the reward of a truncated lane is of the state BEFORE its reset
+          State<float> p;
+          rc_get_state(L.pre, lane, p);
+          float sv2[33];
+          M3<float> Rq2;
+          drone_state<float, true>(p, mk<float>(0.f, 0.f, 0.f), ref_t, e.par, sv2, &Rq2);
+          const float rw2 = reward<float>(spec_reward<SPEC>(a), sv2, act4, (int)info.z, ref_t, a.max_distance, &Rq2);
+          if (rst) rw = rw2;
+        }
+        if (live) {
+          __builtin_nontemporal_store(rw, reward_out + (size_t)(t - 1) * n + i);
+          __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc_out + (size_t)(t - 1) * n + i);
+        }
+        flush_obs_any<SPEC>(L.tile, obs + ((size_t)(t - 1) * n + base_env) * D, min(64, n - base_env), D);
+      }
+      if (t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
+      RC_STAMP(3);
+      if (t < T) coop_barrier();   // 2
+      RC_STAMP(4);
+    }
+  }
+}
+
+hipError_t launch_rollout_coop(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
+  KArgs kk = k;
+  kk.main_blocks = (k.n + 63) / 64;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL((k_rollout_coop<SPEC_RMA>), dim3(kk.main_blocks), dim3(RC_THREADS), 0, stream, kk, T, actions, obs, reward, trunc);
+  return hipGetLastError();
+}
+
+#ifdef QD_STAMPS
+extern "C" int qd_debug_read_rcstamps(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_rcstamps), sizeof(unsigned long long) * 64 * 4 * 16) == hipSuccess ? 0 : -4;
+}
+#endif
+
+}  // namespace qd

@@ -463,22 +463,28 @@ class BaseDroneEnv(_VectorEnvBase):
             trunc.fill_(1)
         return obs, rew, trunc
 
-    def step_fragment_tensor(self, actions, obs, reward, truncated):
+    def step_fragment_tensor(self, actions, obs, reward, truncated, _launch=None):
         """T vector_steps (actions [T,N,4] already on the device) written in place into obs [T,N,D], reward [T,N],
-        truncated [T,N]: one k_step launch per step, issued by ONE C call (launch by launch below 128 steps, replayed from a
-        HIP graph above).  The regen rule of vector_step is applied when the fragment ends on the regen boundary; a fragment
-        that would cross it is cut there."""
+        truncated [T,N] by ONE C call: one persistent kernel launch for the training configuration at small batches
+        (k_rollout_coop), otherwise one k_step launch per step (launch by launch below 128 steps, replayed from a HIP graph
+        above).  The regen rule of vector_step is applied when the fragment ends on the regen boundary; a fragment that would
+        cross it is cut there."""
         T = int(actions.shape[0])
-        if self._reference is not self._ref_pushed:
-            self._push_reference()
-        if self._regen_at and self.total_steps + T > self._regen_at:
-            cut = self._regen_at - self.total_steps
-            self.step_fragment_tensor(actions[:cut], obs[:cut], reward[:cut], truncated[:cut])
-            self.step_fragment_tensor(actions[cut:], obs[cut:], reward[cut:], truncated[cut:])
-            return obs, reward, truncated
         if T == 0:
             return obs, reward, truncated
-        self._dev.step_fragment(actions, obs, reward, truncated)
+        if self._reference is not self._ref_pushed:
+            self._push_reference()
+        if self._regen_at:
+            cut = self._regen_at - self.total_steps
+            if cut <= 0:
+                # only reachable when a caller advanced total_steps past the boundary by hand: the reference's test is `==`
+                # (BaseDroneEnv.py:289), which such a counter never meets again -- no regeneration, no cut
+                cut = T
+            if cut < T:
+                self.step_fragment_tensor(actions[:cut], obs[:cut], reward[:cut], truncated[:cut], _launch)
+                self.step_fragment_tensor(actions[cut:], obs[cut:], reward[cut:], truncated[cut:], _launch)
+                return obs, reward, truncated
+        (_launch or self._dev.step_fragment)(actions, obs, reward, truncated)
         self.total_steps += T
         self._host_cache = self._obs_host = None
         if self._regen_at and self.total_steps == self._regen_at:
@@ -490,13 +496,20 @@ class BaseDroneEnv(_VectorEnvBase):
         return obs, reward, truncated
 
     def rollout_tensor(self, actions):
-        """T steps in one kernel launch: actions [T,N,4] -> (obs [T,N,D], reward [T,N], truncated [T,N])"""
+        """T steps in one kernel launch per regen period: actions [T,N,4] -> (obs [T,N,D], reward [T,N], truncated [T,N]);
+        the regen rule of vector_step is applied like in step_fragment_tensor (a run that crosses the boundary is cut there)"""
         self._push_reference()
-        out = self._dev.rollout(actions)
-        self.total_steps += int(actions.shape[0])
+        dev = self._dev
+        actions = dev._f32(actions, tuple(actions.shape))
+        T = int(actions.shape[0])
+        if tuple(actions.shape[1:]) != (dev.n, 4):
+            raise ValueError("Action dimension mismatch")
+        obs = torch.empty((T, dev.n, dev.D), dtype=torch.float32, device=dev.device)
+        reward = torch.empty((T, dev.n), dtype=torch.float32, device=dev.device)
+        truncated = torch.empty((T, dev.n), dtype=torch.uint8, device=dev.device)
+        self.step_fragment_tensor(actions, obs, reward, truncated, _launch=dev.rollout)
         self._invalidate()
-        self._obs_host = None
-        return out
+        return obs, reward, truncated
 
     # ---- the reference's analytic PID cascade as an on-device action source (attitude_test.py:26-47) ----
     def pid_reset(self, mask=None):

@@ -52,6 +52,8 @@ class DeviceEnv:
         self._qd_step = self.lib.qd_step
         self._obs_ptr, self._rew_ptr, self._trunc_ptr = self.obs.data_ptr(), self.reward.data_ptr(), self.truncated.data_ptr()
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        self.device = torch.device(self.device.type, self._dev_index)   # canonical form: tensors report an indexed device
+        self._frag_ok = None
         L.check(self.lib.qd_init(self.handle, self._stream()))
 
     def __del__(self):
@@ -144,13 +146,24 @@ class DeviceEnv:
         return obs, reward, truncated
 
     def step_fragment(self, actions, obs, reward, truncated):
-        """T per-step launches as one HIP graph (captured on first use for these buffers): actions [T,N,4] -> obs [T,N,D],
-        reward [T,N], truncated [T,N], all caller-owned and reused from call to call"""
+        """T env steps by one C call: actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N], all caller-owned device
+        tensors reused from call to call (one persistent launch, or T per-step launches replayed from a HIP graph captured on
+        first use for these buffers: qd_step_fragment)"""
         T = int(actions.shape[0])
         if tuple(actions.shape[1:]) != (self.n, 4) or actions.dtype != torch.float32 or not actions.is_contiguous():
             raise ValueError("Action dimension mismatch")
         if tuple(obs.shape) != (T, self.n, self.D) or tuple(reward.shape) != (T, self.n) or tuple(truncated.shape) != (T, self.n):
             raise ValueError("fragment buffers must be [T,N,D], [T,N], [T,N]")
+        # the kernels write through these raw pointers: a strided view, another dtype or another device would be written
+        # out of bounds or as garbage.  Validated once per set of buffers (the same tensors come back every fragment).
+        key = (actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), truncated.data_ptr(), T)
+        if key != self._frag_ok:
+            for name, t, dt in (("actions", actions, torch.float32), ("obs", obs, torch.float32), ("reward", reward, torch.float32),
+                                ("truncated", truncated, torch.uint8)):
+                if t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                    raise ValueError("fragment buffer %s must be a contiguous %s tensor on %s (got %s, contiguous=%s, %s)"
+                                     % (name, dt, self.device, t.dtype, t.is_contiguous(), t.device))
+            self._frag_ok = key
         L.check(self.lib.qd_step_fragment(self.handle, actions.data_ptr(), T, obs.data_ptr(), reward.data_ptr(), truncated.data_ptr(),
                                           _raw_stream(self._dev_index)))
         return obs, reward, truncated

@@ -935,9 +935,9 @@ def test_step_fragment_graph_replay_equals_steps(qd):
     fragment boundary"""
     from mujoco_drone_amd.environments.BaseDroneEnv import base_config
     from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
-    from mujoco_drone_amd.environments.rewards import distance_energy_reward
-    n, T = 300, 16
-    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+    from mujoco_drone_amd.environments.rewards import distance_reward_fcn   # (distance_energy_reward at this size is ONE persistent
+    n, T = 300, 16                                                          # launch, tests/test_gpu_fragment.py: no graph to test)
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_reward_fcn, random_params=True, param_difficulty=1,
                state_difficulty=0.2, max_steps=10, regen_env_at_steps=3 * T, auto_reset=True)
     e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
     e1.vector_reset_tensor(); e2.vector_reset_tensor()
@@ -1000,9 +1000,9 @@ def test_step_fragment_policies_long_and_short_runs(qd):
     boundary (128) in between"""
     from mujoco_drone_amd.environments.BaseDroneEnv import base_config
     from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
-    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    from mujoco_drone_amd.environments.rewards import distance_reward_fcn   # a configuration that is stepped launch by launch
     n = 64
-    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_reward_fcn, random_params=True, param_difficulty=1,
                state_difficulty=0.2, max_steps=40, auto_reset=True)
     e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
     e1.vector_reset_tensor(); e2.vector_reset_tensor()
@@ -1159,3 +1159,33 @@ def test_config5_in_kernel_reset_rows_carry_the_refreshed_sensor(qd):
                 assert float(d.max()) < 2e-5, (n, t, float(d.max()))
                 seen += int(idx.numel())
         assert seen > 100, "no truncations: the test did not exercise the reset path"
+
+
+def test_regenerated_parameters_invalidate_the_pools_sensor_form(qd):
+    """A reset-pool entry of a sensor-reading configuration carries the new episode's first accelerometer reading as an affine
+    function of the activations, evaluated with the env's model.  qd_randomize_params / qd_set_params replace that model; an entry
+    prepared before must not serve its old reading after (round 2 did: the first row of every env's next episode and the stored
+    ACC plane then belonged to the previous parameter set).  Checked against a batch past QD_POOL_MAX_ENVS, whose truncating
+    lanes sample and run the forward dynamics inline: env i's rows are bit-identical in both (batch-size independence)."""
+    L, n, big = qd._lib, 128, 32768
+    mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, obs="BaseDroneEnv", reward="distance_energy_reward", start=1,
+                                             random_params=1, auto_reset=1, max_steps=6, seed=21))
+    a, b = mk(n), mk(big)
+    a.reset(); b.reset()
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for t in range(40):
+        if t in (15, 27):                                   # mid-episode: new parameters, then a full reset (what a regen does)
+            a.randomize_params(); b.randomize_params()
+            a.reset(); b.reset()
+        if t == 33:                                         # explicit parameters without a reset
+            raw = rand_raw(np.random.default_rng(2), big, True)
+            a.set_params(raw[:n]); b.set_params(raw)
+        act = torch.rand((big, 4), generator=g, device="cuda")
+        oa, ra, ta = a.step(act[:n].contiguous())
+        ob, rb, tb = b.step(act)
+        assert torch.equal(oa, ob[:n]) and torch.equal(ra, rb[:n]) and torch.equal(ta, tb[:n]), "step %d: max |d obs| %.3e" % (
+            t, float((oa - ob[:n]).abs().max()))
+        sa, sb = a.get_state()[3], b.get_state()[3]          # sensordata: refreshes a stale reading, returns a stored one as it is
+        assert torch.equal(sa, sb[:n]), "step %d: accelerometer plane" % t
+    taken, inline = a.pool_counters()
+    assert taken > 4 * n and inline <= 0.05 * taken          # the small batch did go through the pool

@@ -161,10 +161,10 @@ def test_load_policy_state_reads_rllib_checkpoint_layout(tmp_path):
 
 
 def test_arena_plane_table_matches_the_kernel_source():
-    """environments/_device.py names the arena's float4 planes; the order must be the `enum Group` of csrc/qd_kernels.hip"""
+    """environments/_device.py names the arena's float4 planes; the order must be the `enum Group` of csrc/qd_env_device.h"""
     import re
     from mujoco_drone_amd.environments._device import ARENA_PLANES
-    src = open(os.path.join(ROOT, "mujoco-drone_amd", "csrc", "qd_kernels.hip")).read()
+    src = open(os.path.join(ROOT, "mujoco-drone_amd", "csrc", "qd_env_device.h")).read()
     body = re.search(r"enum Group \{(.*?)NUM_GROUPS", src, re.S).group(1)
     body = re.sub(r"//[^\n]*", "", body)
     names = [m.replace("G_", "") for m in re.findall(r"\b(G_[A-Z0-9]+)\b", body)]
