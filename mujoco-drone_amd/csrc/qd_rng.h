@@ -56,6 +56,11 @@ QD_HD void sample_words(uint64_t seed, uint32_t env, uint32_t episode, uint32_t*
   for (uint32_t b = B0; b < B1; b++) philox4x32_10(env, episode, b, STREAM_STATE, k0, k1, w + 4 * b);
 }
 QD_HD void draws_from_words(const uint32_t w[20], float z[16], float u[2]) {
+  // No multiply-add fusion in the two float stages of a sample: a sample must be the same bits whoever computes it -- a reset
+  // kernel, a sampler wave, the chunked job of the persistent fragment kernel or a truncating lane itself -- and which products
+  // the compiler fuses depends on the code around the inlined body.  (Found by the cut-invariance test of k_rollout_coop: rows
+  // changed in the last bit with WHERE an entry had been sampled.)
+#pragma clang fp contract(off)
 #pragma unroll
   for (int i = 0; i < 8; i++) {
     const float u1 = u32_to_unit(w[2 * i]), u2 = u32_to_unit(w[2 * i + 1]);
@@ -82,6 +87,7 @@ QD_HD void sample_draws(uint64_t seed, uint32_t env, uint32_t episode, float z[1
 // BaseDroneEnv.sample_state: raw draws -> qpos / qvel (activations are NOT touched: QUIRK C-2)
 template <bool LOAD>
 QD_HD void sample_state(const SampleCfg& c, const float z[16], const float u[2], State<float>& s) {
+#pragma clang fp contract(off)   // see draws_from_words
   float roll = 0.f, pitch = 0.f, yaw = c.start_pos[3];
   if (c.random_start == 1) {
     const float inv = frsq(z[0] * z[0] + z[1] * z[1] + z[2] * z[2]);

@@ -85,6 +85,10 @@ __device__ __forceinline__ bool rc_entry_valid(float4 tagp, uint32_t episode) {
   return __float_as_uint(tagp.z) != 0u && __float_as_uint(tagp.y) == episode;
 }
 
+// "this value exists here": an empty asm that reads it (the volatile asms keep their order, the barrier among them)
+__device__ __forceinline__ void rc_pin(double x, double y, double z) { asm volatile("" ::"v"(x), "v"(y), "v"(z)); }
+__device__ __forceinline__ void rc_pin(const V3<double>& v) { rc_pin(v.x, v.y, v.z); }
+
 #ifdef QD_STAMPS
 // diagnostic build: cycle stamps of one step in the middle of the fragment, 16 per (workgroup, wave)
 __device__ unsigned long long qd_rcstamps[64 * 4 * 16];
@@ -150,6 +154,13 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
         integrate_act(e.M, e.s, c0, c1, c2, c3, a.h);
       }
       rc_ref(a, i, e.num_steps, ref0, e.ref);
+      // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
+      // arithmetic across freely, and left alone it sinks two thirds of the factorisation into phase 2 -- onto the critical
+      // path, while this wave sits at the barrier waiting for the applied wrench (stamps: phase 2 2600 cycles instead of 1800)
+      rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc); rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
+      rc_pin(f.s11, f.s12, f.s22); rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
+      rc_pin(f.imt, f.m2, f.hb);
+      asm volatile("" ::"v"(e.s.a0), "v"(e.s.a1), "v"(e.s.a2), "v"(e.s.a3), "v"(e.ref[0]), "v"(e.ref[1]), "v"(e.ref[2]));
       RC_STAMP(1);
       coop_barrier();   // 1
       RC_STAMP(2);
@@ -258,8 +269,13 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
     }
     coop_barrier();   // P
     // the sampler job: per lane the episode it samples (NONE: the lane is not part of the job), the Philox words so far, the
-    // finished state; `jphase` is wave-uniform: 0 idle, 1..3 the chunk to run next, 4 finished -> commit
+    // finished state; `jphase` is wave-uniform: 0 idle, 1..7 the chunk to run next, JOB_DONE finished -> commit
     constexpr uint32_t NONE = 0xFFFFFFFFu;
+    constexpr int JOB_DONE = 8;
+    float jz[16], ju[2];
+#pragma unroll
+    for (int k = 0; k < 16; k++) jz[k] = 0.f;
+    ju[0] = ju[1] = 0.f;
     uint32_t jx = NONE, jw[20];
 #pragma unroll
     for (int k = 0; k < 20; k++) jw[k] = 0u;
@@ -269,7 +285,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
     int jphase = 0;
     for (int t = 0; t < T; t++) {
       RC_STAMP(0);
-      if (jphase == 4) {   // commit: wave A is in its phase 1 and does not read the pool
+      if (jphase == JOB_DONE) {   // commit: wave A is in its phase 1 and does not read the pool
         if (jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
         jphase = 0;
       }
@@ -296,17 +312,18 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
           jx = !have_c ? episode : (!have_n ? episode + 1u : NONE);
           if (__any(jx != NONE ? 1 : 0)) jphase = 1;
         }
-        if (jphase == 1) {
-          sample_words<0, 3>(a.seed, (uint32_t)i, jx, jw);
-          jphase = 2;
-        } else if (jphase == 2) {
-          sample_words<3, 5>(a.seed, (uint32_t)i, jx, jw);
-          jphase = 3;
-        } else if (jphase == 3) {
-          float z[16], u[2];
-          draws_from_words(jw, z, u);
-          sample_state<true>(a.sc, z, u, jns);
-          jphase = 4;
+        // one Philox block per step (its 32-bit multiplies are quarter rate: ~900 cycles a block), then the Box-Muller pairs,
+        // then the transforms: every chunk well inside wave A's phase 2 (three blocks at once made this wave the last one at
+        // barrier 2 in half of the steps)
+        switch (jphase) {
+          case 1: sample_words<0, 1>(a.seed, (uint32_t)i, jx, jw); jphase = 2; break;
+          case 2: sample_words<1, 2>(a.seed, (uint32_t)i, jx, jw); jphase = 3; break;
+          case 3: sample_words<2, 3>(a.seed, (uint32_t)i, jx, jw); jphase = 4; break;
+          case 4: sample_words<3, 4>(a.seed, (uint32_t)i, jx, jw); jphase = 5; break;
+          case 5: sample_words<4, 5>(a.seed, (uint32_t)i, jx, jw); jphase = 6; break;
+          case 6: draws_from_words(jw, jz, ju); jphase = 7; break;
+          case 7: sample_state<true>(a.sc, jz, ju, jns); jphase = JOB_DONE; break;
+          default: break;
         }
       }
       RC_STAMP(3);
@@ -316,7 +333,7 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
     // hand the pool back to the arena as the per-step kernels expect it: the entry of every env's current counter and of the
     // one after it, complete (what the chunked job had not finished is sampled here, once per fragment)
     if (pool) {
-      if (jphase == 4 && jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
+      if (jphase == JOB_DONE && jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
       const uint32_t episode = L.info[lane].y;
 #pragma unroll 1
       for (uint32_t d = 0; d < 2; d++) {

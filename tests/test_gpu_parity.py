@@ -1165,8 +1165,9 @@ def test_regenerated_parameters_invalidate_the_pools_sensor_form(qd):
     """A reset-pool entry of a sensor-reading configuration carries the new episode's first accelerometer reading as an affine
     function of the activations, evaluated with the env's model.  qd_randomize_params / qd_set_params replace that model; an entry
     prepared before must not serve its old reading after (round 2 did: the first row of every env's next episode and the stored
-    ACC plane then belonged to the previous parameter set).  Checked against a batch past QD_POOL_MAX_ENVS, whose truncating
-    lanes sample and run the forward dynamics inline: env i's rows are bit-identical in both (batch-size independence)."""
+    ACC plane then belonged to the previous parameter set: an error of the order of the parameter spread, ~1 m/s^2).  Checked
+    against a batch past QD_POOL_MAX_ENVS, whose truncating lanes sample and run the forward dynamics inline: env i's rows are
+    the same in both up to the rounding between the affine form c0 + sum a_i col_i and the direct evaluation (measured 2e-6)."""
     L, n, big = qd._lib, 128, 32768
     mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, obs="BaseDroneEnv", reward="distance_energy_reward", start=1,
                                              random_params=1, auto_reset=1, max_steps=6, seed=21))
@@ -1183,9 +1184,9 @@ def test_regenerated_parameters_invalidate_the_pools_sensor_form(qd):
         act = torch.rand((big, 4), generator=g, device="cuda")
         oa, ra, ta = a.step(act[:n].contiguous())
         ob, rb, tb = b.step(act)
-        assert torch.equal(oa, ob[:n]) and torch.equal(ra, rb[:n]) and torch.equal(ta, tb[:n]), "step %d: max |d obs| %.3e" % (
-            t, float((oa - ob[:n]).abs().max()))
+        assert torch.equal(ta, tb[:n]) and torch.allclose(oa, ob[:n], rtol=0, atol=1e-4) and torch.allclose(ra, rb[:n], rtol=0, atol=1e-4), \
+            "step %d: max |d obs| %.3e" % (t, float((oa - ob[:n]).abs().max()))
         sa, sb = a.get_state()[3], b.get_state()[3]          # sensordata: refreshes a stale reading, returns a stored one as it is
-        assert torch.equal(sa, sb[:n]), "step %d: accelerometer plane" % t
+        assert torch.allclose(sa, sb[:n], rtol=0, atol=1e-4), "step %d: accelerometer plane %.3e" % (t, float((sa - sb[:n]).abs().max()))
     taken, inline = a.pool_counters()
     assert taken > 4 * n and inline <= 0.05 * taken          # the small batch did go through the pool
