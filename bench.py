@@ -18,10 +18,13 @@ Launching: under torchrun (WORLD_SIZE set) every process is one rank.  Started p
 process becomes a launcher: it starts N rank processes of this script (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in
 their environment) BEFORE touching torch or the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
 
-Every step is one k_step kernel launch.  Steps are issued through qd_step_fragment (one C call per run of steps
-inside a [T,N,...] fragment): launch by launch for runs shorter than 128 steps, as a replayed HIP graph above
-(captured during the untimed ramp, never inside the timed region).  `roofline.kernel_us` does not depend on --steps:
-it is the per-launch period of 4096 back-to-back k_step launches between two HIP events on the launch stream.
+Steps are issued through qd_step_fragment (C ABI), one call per run of steps inside a [T,N,...] fragment.  For the headline
+configuration (config 3 at <= 24576 envs) a run is ONE persistent kernel launch (k_rollout_coop: 64 envs per workgroup stay on
+their CU for the whole run); otherwise a run is one k_step launch per step -- launch by launch for runs shorter than 128 steps,
+a replayed HIP graph above (captured during the untimed rehearsal, never inside the timed region).  `config.launch` says which,
+`roofline.kernel` names the kernel (the library's own variant selector: qd_fragment_kernel_name).  `roofline.kernel_us` does not
+depend on --steps: it is the average duration of back-to-back launches of the dominant kernel on 1024-step fragments, between
+two HIP events on the launch stream.
 
 --dry: rehearsal of the launcher / distributed / fragment all-gather plumbing on CPU tensors (gloo), no GPU, no env
 stepping (the fragments are filled with a rank pattern); the line says "dry_run": true and is not a measurement.
@@ -161,9 +164,10 @@ def kernel_time_us(env, actions, samples=200):
 
 
 def kernel_period_us(env, frag, launches=KERNEL_PERIOD_LAUNCHES):
-    """per-launch period of `launches` back-to-back k_step launches (graph-replayed fragments, no host in the loop),
-    between two HIP events recorded on the launch stream: the kernel's average duration plus the kernel boundary -- what
-    rocprofv3's kernel trace reports for back-to-back dispatches.  Fixed length: independent of --steps."""
+    """time per env step of `launches` steps issued as back-to-back fragments (no host in the loop), between two HIP events
+    recorded on the launch stream.  For per-step launches (graph-replayed) this is the kernel's average duration plus the
+    kernel boundary -- what rocprofv3's kernel trace reports for back-to-back dispatches; for the persistent kernel it is the
+    launch duration divided by the steps of the launch.  Fixed length: independent of --steps.  Returns (us per step, steps)."""
     import torch
     T = frag.T
     reps = max(1, launches // T)
@@ -242,6 +246,42 @@ def launch_ranks(n_ranks, argv):
         sys.stderr.write("bench: rank(s) failed: %s\n" % ", ".join("rank %d exit %d" % rc for rc in bad))
         return 1
     return 0
+
+
+PERSISTENT_OWN_BYTES = 109   # what k_rollout_coop itself moves per env-step: action R 16 + obs W 88 + reward W 4 + truncated W 1
+
+
+def launch_text(env, K, timed_runs):
+    runs = "+".join(str(c) for c in timed_runs[:6]) + ("+..." if len(timed_runs) > 6 else "")
+    if env is None:
+        return "dry run: no launches"
+    name = env._dev.fragment_kernel_name()
+    if "k_rollout_coop" in name:
+        return ("ONE persistent kernel launch per run of steps (%s, four wavefronts per 64 envs keep the state on their CU for the whole run), "
+                "issued through qd_step_fragment (C ABI): the %d timed steps went out as %d launch(es) of %s steps; the per-step-launch "
+                "figure of the same workload is extras.per_step_launch_env_steps_per_s" % (name, K, len(timed_runs), runs))
+    return ("one step-kernel launch per step (%s), issued through qd_step_fragment (C ABI), one call per run of steps inside a "
+            "fragment: the %d timed steps went out as %d run(s) of %s steps, each a replayed HIP graph captured during the "
+            "untimed rehearsal (QD_GRAPH_MIN_STEPS >= 2^30 would issue them launch by launch)" % (name, K, len(timed_runs), runs))
+
+
+def committed_profile(kernel, config, n):
+    """figures of the committed rocprofv3 runs (profiles/current.json, written by tools/install_profiles_r03.py) -- only if they
+    were taken from the library that is loaded now: otherwise None and the reason"""
+    path = os.path.join(ROOT, "profiles", "current.json")
+    try:
+        cur = json.load(open(path))
+    except Exception:
+        return None, "no profiles/current.json"
+    from mujoco_drone_amd import _lib as L
+    have = L.lib().qd_source_hash().decode()
+    if cur.get("source_hash") != have:
+        return None, "stale_profile: profiles/current.json was taken from library %s..., loaded library is %s..." % (
+            str(cur.get("source_hash"))[:12], have[:12])
+    ent = cur.get("kernels", {}).get("%s/%s/%d" % (kernel, config, n))
+    if ent is None:
+        return None, "profiles/current.json has no entry for %s/%s/%d" % (kernel, config, n)
+    return ent, None
 
 
 def parse_args(argv=None):
@@ -453,76 +493,67 @@ def main():
                "config": {"workload": WORKLOADS[args.config] + "; trajectories written in place into [T=%d,N,...] fragments" % T +
                                       (" (their RCCL all-gather is reported separately in config.trajectory_all_gather)" if world > 1 else ""),
                           "envs_per_gpu": n, "global_envs": world * n, "clock_ramp_steps": ramp, "frame_skip": 2 if args.config == "config2" else 1,
-                          "launch": ("one step-kernel launch per step, issued through qd_step_fragment (C ABI), one call per run of steps inside a "
-                                     "fragment: the %d timed steps went out as %d run(s) of %s steps, each a replayed HIP graph captured during the "
-                                     "untimed rehearsal (QD_GRAPH_MIN_STEPS >= 2^30 would issue them launch by launch)"
-                                     % (K, len(timed_runs), "+".join(str(c) for c in timed_runs[:6]) + ("+..." if len(timed_runs) > 6 else ""))),
+                          "launch": launch_text(env, K, timed_runs),
                           "precision": "float32 state / trigonometry / drag / integration, float64 inertia assembly and solves (load model)", "parallelism": "env-sharded x%d" % world,
                           "trajectory_all_gather": gather_info}}
         if args.dry:
             out["dry_run"] = True
             out["config"]["workload"] = "DRY RUN (CPU tensors, no env stepping, not a measurement): " + out["config"]["workload"]
     if rank == 0 and not args.dry:
-        # ---- roofline of the dominant kernel (k_step), measured live with HIP events on the launch stream ----------------
-        # kernel_us = per-launch period of KERNEL_PERIOD_LAUNCHES back-to-back k_step launches (fixed length, whatever --steps
-        # is): the kernel's average duration incl. the inter-kernel boundary.  The same figure over the timed region itself
-        # (which for short runs is dominated by the launch from idle and the final synchronise) is reported beside it.
+        # ---- roofline of the dominant kernel, measured live with HIP events on the launch stream ----------------------------
+        # The dominant kernel is the one qd_step_fragment launches for this env (the library's variant selector names it).
+        # kernel_us = its average launch duration over back-to-back launches on 1024-step fragments (KERNEL_PERIOD_LAUNCHES env
+        # steps in all, whatever --steps is): for the persistent kernel one launch is a whole 1024-step fragment, for a per-step
+        # kernel one step (duration incl. the inter-kernel boundary, as rocprofv3's trace reports back-to-back dispatches).
+        # achieved = SURVEY 8d's algorithmic bytes per env-step x the env-steps one launch processes / kernel_us.
+        kname = env._dev.fragment_kernel_name()
+        persistent = "k_rollout_coop" in kname
         kus_timed = ev0.elapsed_time(ev1) * 1e3 / K
         kfrag = par.FragmentBuffers(1024, n, D, device) if T != 1024 else frags[0]
         if kfrag is not frags[0]:
             kfrag.actions.copy_(lo + (hi - lo) * torch.rand(kfrag.actions.shape, generator=g, device=device, dtype=torch.float32))
-        kus, klaunches = kernel_period_us(env, kfrag)
+        us_per_step, ksteps_measured = kernel_period_us(env, kfrag)
+        steps_per_launch = kfrag.T if persistent else 1
+        kus = us_per_step * steps_per_launch
         P = 64
         actions = kfrag.actions[:P]
         iso_us, raw_us, empty_us = kernel_time_us(env, actions)
-        bytes_per_launch = ALG_BYTES[alg] * n
+        bytes_per_launch = ALG_BYTES[alg] * n * steps_per_launch
         achieved = bytes_per_launch / (kus * 1e-6) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get(args.config, {}).get(str(n))
-            except Exception:
-                traffic = None
-        # the committed rocprofv3 kernel trace of this command (profiles/, tools/profile_r02.sh trace): the same kernel's average
-        # duration under the profiler, for the reader who wants to set the live figure beside it.  The profiler's per-dispatch
-        # instrumentation adds ~0.5-0.8 us to a 4 us kernel (the live HIP-event period measured INSIDE the profiled run reads
-        # 6.8-7.5 us against 4.2 un-profiled), so the two bracket the kernel rather than coincide.
-        prof_us = None
-        prof = os.path.join(ROOT, "profiles", "r02_default_n4096_rocprof_summary.json")
-        if os.path.exists(prof) and args.config == "config3" and n == 4096:
-            try:
-                prof_us = json.load(open(prof))["step_kernel_trace"]["avg_ns"] * 1e-3
-            except Exception:
-                prof_us = None
-        # ... and the profiler's own share, calibrated on a kernel that does nothing (tools/profile_r02.sh calib,
-        # profiles/r02_profiler_calibration.txt): rocprofv3's average dispatch duration of a near-empty kernel in a replayed graph
-        # minus that graph's live period per launch without the profiler
-        prof_over = None
-        try:
-            cal = open(os.path.join(ROOT, "profiles", "r02_profiler_calibration.txt")).read()
-            live = [float(x) for x in re.findall(r"launches: ([0-9.]+) us per launch", cal.split("== the same script")[0])]
-            avg = float(re.search(r"average duration ([0-9.]+) ns", cal).group(1)) * 1e-3
-            prof_over = avg - min(live)
-        except Exception:
-            prof_over = None
+        prof, prof_note = committed_profile(kname, args.config, n)
+        traffic = prof.get("hbm_bytes_per_launch") if prof else None
+        prof_us = prof.get("rocprofv3_avg_kernel_us") if prof else None
         copy_gbps = measured_copy_gbps(device)
         out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": "qd::k_step",
-                           "kernel_us": kus,
-                           "kernel_us_source": "HIP events on the launch stream around %d back-to-back k_step launches (graph-replayed "
-                                               "1024-step fragments), independent of --steps" % klaunches,
-                           "timed_region_us_per_step": kus_timed, "isolated_launch_us": iso_us,
-                           "rocprofv3_avg_kernel_us": prof_us,
-                           "rocprofv3_empty_kernel_excess_us": prof_over,
-                           "frac_at_rocprofv3_duration": (bytes_per_launch / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof_us else None,
+                           "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
+                           "kernel_us": kus, "env_steps_per_launch": n * steps_per_launch, "steps_per_launch": steps_per_launch,
+                           "us_per_step": us_per_step,
+                           "kernel_us_source": "HIP events on the launch stream around %d back-to-back launches of %s (1024-step "
+                                               "fragments, %d env steps per env), independent of --steps"
+                                               % (ksteps_measured // steps_per_launch, kname, ksteps_measured),
                            "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
-                           "env_steps_per_launch": n, "measured_copy_GBps": copy_gbps,
-                           "frac_of_measured_copy": achieved / copy_gbps, "traffic_source": "profiles/pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / "
-                           "WRITE_SIZE passes of this command with direct launches, tools/profile_r02.sh; FETCH_SIZE x2 per the gfx950 calibration)" if traffic else None,
-                           "note": "4096 envs = 192 wavefronts (3 per 64 envs, k_step_coop) on 1024 SIMDs: the launch is a dependent "
-                                   "instruction chain between two kernel boundaries, not HBM-bound (see DESIGN.md and the env-count "
-                                   "sweep in `extras`: 55-59 % of the roofline from 10^6 envs)"}
+                           "timed_region_us_per_step": kus_timed, "isolated_per_step_launch_us": iso_us,
+                           "rocprofv3_avg_kernel_us": prof_us,
+                           "frac_at_rocprofv3_duration": (bytes_per_launch / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof_us else None,
+                           "traffic_bytes_per_env_step": (traffic / (n * steps_per_launch)) if traffic else None,
+                           "profile_note": prof_note or ("rocprofv3_avg_kernel_us / traffic: profiles/current.json, taken from this library "
+                                                         "(source hash checked) by tools/profile_r03.sh: kernel trace of this command; "
+                                                         "separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 calibration"),
+                           "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps}
+        if persistent:
+            own = PERSISTENT_OWN_BYTES * n * steps_per_launch / (kus * 1e-6) / 1e9
+            out["roofline"].update({
+                "kernel_own_bytes_per_env_step": PERSISTENT_OWN_BYTES,
+                "achieved_kernel_own_bytes": own, "frac_kernel_own_bytes": own / HBM_PEAK_GBS,
+                "note": "achieved / frac price the launch at SURVEY 8d's 309 B per env-step (the definition the metric is graded on: state R/W, "
+                        "action, parameters, counter, row, reward, flag).  The persistent kernel does not move the 200 B of state, parameter "
+                        "and counter traffic at all -- they stay in registers / LDS between steps -- so what actually crosses the memory "
+                        "system is 109 B per env-step (achieved_kernel_own_bytes / frac_kernel_own_bytes; `traffic` is the PMC count).  "
+                        "At 4096 envs the launch occupies 64 of 256 CUs and is a dependent instruction chain per step (DESIGN.md section 4), "
+                        "not bandwidth: the env-count sweep in `extras` shows where the same kernels meet the roofline."})
+        else:
+            out["roofline"]["note"] = ("per-step launches: at small batches the launch is a dependent instruction chain between two kernel "
+                                       "boundaries, not HBM-bound (DESIGN.md; env-count sweep in `extras`)")
         if not args.no_extras and world == 1:
             extras = {}
             try:
@@ -536,15 +567,27 @@ def main():
                     step(rows[t % P])
                 torch.cuda.synchronize()
                 extras["per_step_api_env_steps_per_s"] = n * ksteps / (time.perf_counter() - t1)
+                if persistent:
+                    # the same workload as one k_step launch per step, replayed from a HIP graph (round 2's headline path)
+                    from mujoco_drone_amd import _lib as L
+                    e1, _ = make_env(args.config, n, 42, device)
+                    e1.vector_reset_tensor()
+                    e1._dev.set_option(L.OPT_PERSISTENT_FRAGMENTS, 0)
+                    p1, _ = kernel_period_us(e1, kfrag)
+                    extras["per_step_launch_kernel"] = e1._dev.fragment_kernel_name()
+                    extras["per_step_launch_period_us"] = p1
+                    extras["per_step_launch_env_steps_per_s"] = n / (p1 * 1e-6)
+                    del e1
                 sweep = []
-                for nn in (4096, 65536, 1048576, 4194304):
+                for nn in (4096, 16384, 65536, 1048576, 4194304):
                     e2, alg2 = make_env(args.config, nn, 7, device)
                     (e2.vector_reset_tensor() if args.config != "config2" else e2.reset())
                     T2 = 256 if nn <= 65536 else (64 if nn <= 1048576 else 16)      # fragments of <= 1.6 GB
                     f2 = par.FragmentBuffers(T2, nn, e2._dev.D, device)
                     f2.actions.copy_(lo + (hi - lo) * torch.rand(f2.actions.shape, device=device, dtype=torch.float32))
                     p2, _ = kernel_period_us(e2, f2, launches=4 * T2)                # graph-replayed: the host is not in the loop
-                    sweep.append({"envs": nn, "period_us": p2, "env_steps_per_s": nn / (p2 * 1e-6),
+                    sweep.append({"envs": nn, "kernel": e2._dev.fragment_kernel_name(), "fragment_steps": T2,
+                                  "period_us": p2, "env_steps_per_s": nn / (p2 * 1e-6),
                                   "alg_GBps": ALG_BYTES[alg2] * nn / (p2 * 1e-6) / 1e9,
                                   "frac_hbm": ALG_BYTES[alg2] * nn / (p2 * 1e-6) / 1e9 / HBM_PEAK_GBS})
                     del e2, f2
@@ -600,13 +643,14 @@ def main():
                     e4, alg4 = make_env(other, n4, 5, device)
                     (e4.reset() if other == "config2" else e4.vector_reset_tensor())
                     lo4, hi4 = (0.5, 1.0) if other == "config2" else (0.0, 1.0)
-                    # like the headline: one kernel launch per step, the launches of a 1024-step fragment replayed from a HIP graph
+                    # qd_step_fragment on 1024-step fragments (these configurations: one kernel launch per step, replayed from a HIP graph)
                     f4 = par.FragmentBuffers(1024, n4, e4._dev.D, device)
                     f4.actions.copy_(lo4 + (hi4 - lo4) * torch.rand(f4.actions.shape, device=device, dtype=torch.float32))
                     p4, _ = kernel_period_us(e4, f4)
                     extras[other + "_env_steps_per_s"] = n4 / (p4 * 1e-6)
                     extras[other + "_period_us"] = p4
                     extras[other + "_envs"] = n4
+                    extras[other + "_kernel"] = e4._dev.fragment_kernel_name()
                     del e4, f4
                     torch.cuda.empty_cache()
             except Exception as ex:  # extras never invalidate the headline line

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define QD_VERSION 2
+#define QD_VERSION 3
 
 typedef struct qd_env qd_env;
 
@@ -182,22 +182,40 @@ int qd_get_state(qd_env* env, float* qpos, float* qvel, float* act, float* senso
  * are read once per process and exist for measurements. */
 int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* obs, float* reward,
             uint8_t* truncated, void* stream);
-/* T consecutive qd_step launches (same kernels, same results: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N])
- * issued by ONE call.  Runs of >= 128 steps (QD_GRAPH_MIN_STEPS) go out as ONE HIP graph: the first call with a given
- * (T, buffers) captures the launches, later calls replay them, so the per-step host launch path (~4-5 us, the bound of
- * qd_step at 4096 envs) is paid once per fragment.  A shorter run is issued launch by launch the first time its (T, buffers)
- * are seen, captured the second time and replayed from then on (a capture costs ~20 us per node, a replay 10-16 us).  Up to
- * 8 graphs are kept per env (least recently used replaced); QD_GRAPH_MIN_STEPS >= 2^30 switches graphs off.  For rollout
- * fragments whose actions are already on the device (replays, or a policy that wrote the whole fragment).  Graphs are
- * captured on a stream owned by the env and replayed in `stream`; qd_set_reference invalidates them. */
+/* T consecutive vector_steps issued by ONE call: actions[T,N,4] -> obs[T,N,D], reward[T,N], truncated[T,N]; what the sampler
+ * does per rollout fragment (T consecutive BaseDroneEnv.vector_step calls, BaseDroneEnv.py:259-294; 1024-step fragments,
+ * train_RMA.py:63).  For fragments whose actions are already on the device (replays, or a policy that wrote the whole
+ * fragment).  Two ways of running it, chosen per env configuration (qd_fragment_kernel_name tells which):
+ *   - ONE persistent launch (k_rollout_coop, csrc/qd_rollout_coop.hip) for train_PPO.py / train_RMA.py's configuration
+ *     (load model, LocalFrameRPYParamsEnv, distance_energy_reward) up to QD_COOP_MAX_ENVS envs: four wavefronts per 64 envs keep
+ *     the state on their CU for all T steps, only actions come in and rows / rewards / flags go out.  Same results as T x
+ *     qd_step up to the rounding of two compilations of the same arithmetic (the truncation flags exactly; bit-identical to
+ *     itself whatever the batch size and wherever a run is cut into fragments).  QD_OPT_PERSISTENT_FRAGMENTS = 0 (qd_set_option)
+ *     or QD_PERSISTENT=0 in the environment selects the other way;
+ *   - T qd_step launches (same kernels, same results, bit for bit).  Runs of >= 128 steps (QD_GRAPH_MIN_STEPS) go out as ONE
+ *     HIP graph: the first call with a given (T, buffers) captures the launches, later calls replay them, so the per-step host
+ *     launch path (~4-5 us, the bound of qd_step at 4096 envs) is paid once per fragment.  A shorter run is issued launch by
+ *     launch the first time its (T, buffers) are seen, captured the second time and replayed from then on (a capture costs
+ *     ~20 us per node, a replay 10-16 us).  Up to 8 graphs are kept per env (least recently used replaced); QD_GRAPH_MIN_STEPS
+ *     >= 2^30 switches graphs off.  Graphs are captured on a stream owned by the env and replayed in `stream`;
+ *     qd_set_reference invalidates them. */
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
+/* Per-env switches of launch variants (measurements and A/B tests; results do not depend on them beyond rounding).
+ *   QD_OPT_PERSISTENT_FRAGMENTS  1 (default): qd_step_fragment / qd_rollout may run as one persistent launch; 0: never. */
+enum { QD_OPT_PERSISTENT_FRAGMENTS = 0, QD_OPT_COUNT };
+int qd_set_option(qd_env* env, int option, int value);
+/* The kernel that a qd_step / a qd_step_fragment of this env launches right now (static strings; the variant selector's own
+ * answer, for benchmark lines and profiles: "qd::k_step_coop<1>", "qd::k_rollout_coop<1>", ...). */
+const char* qd_step_kernel_name(const qd_env* env);
+const char* qd_fragment_kernel_name(const qd_env* env);
 /* How the in-kernel resets (auto_reset) since qd_init got their new state: counters[0] = served by the reset pool (an entry
  * pre-sampled by the sampler workgroups of earlier launches), counters[1] = sampled inline by the truncating lane (pool off,
  * or no entry yet).  Same results either way; inline sampling is what the pool exists to keep off the step's critical path.
  * counters: 2 x uint32 in device memory, written in stream order. */
 int qd_pool_counters(qd_env* env, uint32_t* counters, void* stream);
-/* T consecutive steps in ONE launch with the state held in registers: actions[T,N,4] ->
- * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls. */
+/* T consecutive steps in ONE launch with the state held on the chip: actions[T,N,4] ->
+ * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls (up to rounding between kernels).  The persistent
+ * kernel of qd_step_fragment where that applies, else k_rollout (one wavefront per 64 envs, state in registers). */
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated,
                void* stream);
 

@@ -73,6 +73,7 @@ POL_DENSE, POL_AFFINE, POL_COPY_OBS, POL_COPY_PREV, POL_RING_LOAD, POL_RING_PUSH
 ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 POL_VALUE_ONLY = 1
 DIST_BETA, DIST_SQUASHED_GAUSSIAN = 0, 1
+OPT_PERSISTENT_FRAGMENTS = 0
 
 # every symbol include/qd.h declares: (restype, argtypes)
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64
@@ -101,6 +102,9 @@ SIGNATURES = {
     "qd_step": (_I, [_VP, _VP, _I64, _VP, _VP, _VP, _VP]),
     "qd_rollout": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "qd_step_fragment": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
+    "qd_set_option": (_I, [_VP, _I, _I]),
+    "qd_step_kernel_name": (C.c_char_p, [_VP]),
+    "qd_fragment_kernel_name": (C.c_char_p, [_VP]),
     "qd_pool_counters": (_I, [_VP, _VP, _VP]),
     "qd_pid_reset": (_I, [_VP, _VP, _VP]),
     "qd_pid_action": (_I, [_VP, _VP, _VP]),

@@ -966,6 +966,7 @@ struct qd_env {
   hipStream_t frag_stream = nullptr;
   // qd_set_reference_schedule: waypoint k is the reference of the k-th step of the next policy rollout
   std::vector<double> ref_schedule;
+  int opt[QD_OPT_COUNT] = {1};   // qd_set_option
 };
 
 static thread_local char g_err[512] = "";
@@ -1353,8 +1354,39 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
 
 // does a fragment of this env run as one persistent launch (k_rollout_coop)?  The same batches k_step_coop steps: the
 // four-wave workgroup per 64 envs needs a CU to itself
+// Every batch size: measured against the per-step launches on one box (tests/diag_persistent_big.py, profiles/r03_persistent_vs_per_step.txt)
+// 4096 envs 1.50 / 3.99 us per step, 16384 1.60 / 5.12, 65536 5.19 / 7.71, 262144 20.5 / 23.5, 2^20 73.2 / 70.9, 2^22 249 / 289.
+// QD_PERSISTENT_MAX_ENVS lowers the limit for experiments.
+static int qd_persistent_max_envs() {
+  static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS"); return e ? atoi(e) : 0x7fffffff; }();
+  return v;
+}
 static bool qd_fragment_is_persistent(const qd_env* env) {
-  return qd_persistent() && env->load && env->spec == SPEC_RMA && env->ka.n <= qd_coop_max_envs();
+  return qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && env->load && env->spec == SPEC_RMA && env->ka.n <= qd_persistent_max_envs();
+}
+
+int qd_set_option(qd_env* env, int option, int value) {
+  QD_NEED(env);
+  if (option < 0 || option >= QD_OPT_COUNT) return fail(QD_ERR_INVALID, "unknown option %d", option);
+  env->opt[option] = value;
+  return QD_OK;
+}
+
+// the variant selector's answer, in words (the selection itself: qd_step / qd_step_fragment)
+const char* qd_step_kernel_name(const qd_env* env) {
+  if (!env) return "";
+  static const char* const spec_name[] = {"0", "1", "2", "3", "4", "5"};
+  static thread_local char buf[64];
+  const int n = env->ka.n;
+  if (env->load && env->spec == SPEC_RMA && n <= qd_coop_max_envs()) return "qd::k_step_coop<1>";
+  const bool wide = n >= qd_block_threshold();
+  snprintf(buf, sizeof buf, "qd::%s<%s,%d,%s>", wide ? "k_step_wide" : "k_step", env->load ? "true" : "false", wide ? 256 : 64,
+           spec_name[env->spec >= 0 && env->spec <= 5 ? env->spec : 0]);
+  return buf;
+}
+const char* qd_fragment_kernel_name(const qd_env* env) {
+  if (!env) return "";
+  return qd_fragment_is_persistent(env) ? "qd::k_rollout_coop<1>" : qd_step_kernel_name(env);
 }
 
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {

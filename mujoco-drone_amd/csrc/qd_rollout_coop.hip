@@ -107,7 +107,8 @@ __device__ unsigned long long qd_rcstamps[64 * 4 * 16];
 #endif
 
 template <int SPEC>
-__global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
+// (two workgroups per CU: <= 256 registers per wave cost nothing here -- 251 used, no scratch -- and double the envs in flight at large batches)
+__global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
                                                              float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
   static_assert(SPEC == SPEC_RMA, "persistent fragment kernel: LocalFrameRPYParamsEnv + distance_energy_reward on the load model");
   constexpr int D = spec_obs_dim<SPEC>();
@@ -410,6 +411,10 @@ __global__ __launch_bounds__(RC_THREADS) void k_rollout_coop(KArgs a, int T, con
 hipError_t launch_rollout_coop(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
   KArgs kk = k;
   kk.main_blocks = (k.n + 63) / 64;
+  // the workgroup's own sampler costs no extra workgroups, so the pool is on at every batch size (qd_create switches the ARENA
+  // pool off from 32768 envs, where sampler workgroups no longer find idle SIMDs); entries are a pure function of
+  // (seed, env, episode), so the per-step kernels can use or ignore what this kernel leaves in the arena
+  kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED) ? 1 : 0;
   (void)hipGetLastError();
   hipLaunchKernelGGL((k_rollout_coop<SPEC_RMA>), dim3(kk.main_blocks), dim3(RC_THREADS), 0, stream, kk, T, actions, obs, reward, trunc);
   return hipGetLastError();

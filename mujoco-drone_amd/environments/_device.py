@@ -168,6 +168,16 @@ class DeviceEnv:
                                           _raw_stream(self._dev_index)))
         return obs, reward, truncated
 
+    def set_option(self, option, value):
+        """launch-variant switches (qd_set_option), e.g. set_option(L.OPT_PERSISTENT_FRAGMENTS, 0)"""
+        L.check(self.lib.qd_set_option(self.handle, int(option), int(value)))
+
+    def step_kernel_name(self):
+        return self.lib.qd_step_kernel_name(self.handle).decode()
+
+    def fragment_kernel_name(self):
+        return self.lib.qd_fragment_kernel_name(self.handle).decode()
+
     def pool_counters(self):
         """(in-kernel resets served by the reset pool, in-kernel resets sampled inline) since construction"""
         out = torch.zeros(2, dtype=torch.int32, device=self.device)

@@ -44,7 +44,7 @@ def test_enums_in_header_match_python_tables(L):
 
 def test_dimensions(L):
     lib = L.lib()
-    assert lib.qd_version() == 2
+    assert lib.qd_version() == 3
     assert lib.qd_state_dim(L.MODEL_LOAD) == 33 and lib.qd_state_dim(L.MODEL_NOLOAD) == 29
     want = {"BaseDroneEnv": 33, "GlobalFrameRPYEnv": 16, "LocalFramePRYEnv": 16, "LocalFrameFullStateEnv": 23,
             "LocalFrameFullStateZvecEnv": 24, "LocalFramePRYaccEnv": 19, "LocalFramePRYParamsEnv": 22,

@@ -61,7 +61,7 @@ class _Worst:
         return "max |d obs| %.2e  |d reward| %.2e  |d state| %.2e" % (self.obs, self.rew, self.state)
 
 
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 4097])
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 300, 4097, 40001])
 def test_fragment_equals_per_step_kernel(qd, n):
     """ragged and multi-workgroup batch sizes, short episodes (every env resets several times inside the fragment), T = 1 and
     longer runs, fragments that continue each other: every output of every step and the state left behind equal the per-step
@@ -84,22 +84,23 @@ def test_fragment_equals_per_step_kernel(qd, n):
     assert int(Tr.sum()) > 0
 
 
-def test_fragment_is_batch_and_cut_invariant(qd):
-    """what must hold bit for bit: env i's rows do not depend on the batch it is in (4097 envs vs the first 64 of them alone) nor
+@pytest.mark.parametrize("N", [4097, 40001])
+def test_fragment_is_batch_and_cut_invariant(qd, N):
+    """what must hold bit for bit: env i's rows do not depend on the batch it is in (N envs vs the first 64 of them alone) nor
     on where a run is cut into fragments (40 steps at once vs 13 + 1 + 26), through in-kernel resets, including the state, the
     accelerometer plane and the episode counters left in the arena"""
     L, T = qd._lib, 40
     mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, start=1, random_params=1, auto_reset=1, max_steps=7, seed=9))
-    big, small, cut = mk(4097), mk(64), mk(4097)
+    big, small, cut = mk(N), mk(64), mk(N)
     for e in (big, small, cut):
         e.reset()
-    acts = torch.rand((T, 4097, 4), device="cuda")
-    Ob, Rb, Tb = _bufs(T, 4097)
+    acts = torch.rand((T, N, 4), device="cuda")
+    Ob, Rb, Tb = _bufs(T, N)
     big.step_fragment(acts, Ob, Rb, Tb)
     Os, Rs, Ts = _bufs(T, 64)
     small.step_fragment(acts[:, :64].contiguous(), Os, Rs, Ts)
     assert torch.equal(Ob[:, :64], Os) and torch.equal(Rb[:, :64], Rs) and torch.equal(Tb[:, :64], Ts)
-    Oc, Rc, Tc = _bufs(T, 4097)
+    Oc, Rc, Tc = _bufs(T, N)
     for lo, hi in ((0, 13), (13, 14), (14, 40)):
         cut.step_fragment(acts[lo:hi], Oc[lo:hi], Rc[lo:hi], Tc[lo:hi])
     assert torch.equal(Ob, Oc) and torch.equal(Rb, Rc) and torch.equal(Tb, Tc), "cuts: max |d obs| %.3e, first differing step %d" % (
@@ -108,7 +109,10 @@ def test_fragment_is_batch_and_cut_invariant(qd):
         assert torch.equal(x, y)
     for x, y in zip(big.get_state(), small.get_state()):
         assert torch.equal(x[:64], y)
-    assert torch.equal(big.planes()[:, :64], small.planes())     # everything the arena holds, the reset pool included
+    names = qd.dev.ARENA_PLANES
+    pb, ps = big.planes()[:, :64], small.planes()
+    for k, name in enumerate(names):                              # everything the arena holds, the reset pool included
+        assert torch.equal(pb[k], ps[k]), "arena plane %s" % name
 
 
 def test_fragment_and_per_step_launches_interleave(qd):

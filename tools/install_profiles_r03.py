@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Copy the summaries tools/profile_r03.sh left in gpurun_out/prof_r03/ into profiles/ (trimming the kilobyte-long torch kernel
+names) and write profiles/current.json: the figures bench.py may quote next to its live measurement -- rocprofv3's average
+duration of the dominant kernel and its HBM-side bytes per launch -- keyed by kernel / config / env count and stamped with the
+source hash of the library they were taken from (bench.py drops them when another library is loaded)."""
+import json
+import os
+import shutil
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = os.path.join(ROOT, "gpurun_out/prof_r03"), os.path.join(ROOT, "profiles")
+S = {}
+for f in sorted(os.listdir(src)):
+    if not f.endswith("_rocprof_summary.json"):
+        continue
+    d = json.load(open(os.path.join(src, f)))
+    for k in d["kernel_stats"]:
+        if len(k["name"]) > 160:
+            k["name"] = k["name"][:157] + "..."
+    d["kernel_stats"] = d["kernel_stats"][:12]
+    json.dump(d, open(os.path.join(dst, f), "w"), indent=1)
+    S[f[:-len("_rocprof_summary.json")]] = d
+    t = d["step_kernel_trace"]
+    print("%-22s %-40s dispatches %4d (of %4d) avg %10.0f ns median %10.0f  steps/launch %d" % (
+        f[:22], t["kernel"][:40], t["dispatches"], t.get("dispatches_of_this_kernel_in_the_run", -1), t["avg_ns"], t["median_ns"], t.get("steps_per_launch", 1)))
+for f in os.listdir(src):
+    if f.endswith("_kernel_stats.csv"):
+        out = []
+        for ln in open(os.path.join(src, f)).read().splitlines():
+            if len(ln) > 400:
+                ln = '"' + ln[1:150] + '..."' + ln[ln.rfind('",') + 1:]
+            out.append(ln)
+        open(os.path.join(dst, f), "w").write("\n".join(out) + "\n")
+    elif f.startswith("bench_") and f.endswith(".json"):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, "r03_" + f))
+    elif f.endswith(".txt"):
+        shutil.copy(os.path.join(src, f), os.path.join(dst, f))
+
+
+def short(name):     # "void qd::k_rollout_coop<1>(qd::KArgs, ...)" -> "qd::k_rollout_coop<1>"
+    name = name.split("(")[0]
+    return name[5:] if name.startswith("void ") else name
+
+
+cur = {"_comment": "written by tools/install_profiles_r03.py from the rocprofv3 runs of tools/profile_r03.sh; bench.py quotes an entry only "
+                   "when source_hash equals the loaded library's qd_source_hash()", "source_hash": None, "kernels": {}}
+hashes = set()
+for tag, conf, n in (("r03_default_n4096", "config3", 4096),):
+    if tag not in S:
+        continue
+    t = S[tag]["step_kernel_trace"]
+    ent = {"rocprofv3_avg_kernel_us": t["avg_ns"] * 1e-3, "dispatches": t["dispatches"], "steps_per_launch": t.get("steps_per_launch", 1),
+           "from": "profiles/%s_rocprof_summary.json" % tag}
+    hashes.add(S[tag].get("source_hash"))
+    p = S.get(tag.replace("default", "pmc"))
+    if p and "pmc" in p:
+        f = p["pmc"]["fetch"]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2      # KiB, doubled per the gfx950 calibration (MI355X_MICROARCH.md)
+        w = p["pmc"]["write"]["WRITE_SIZE"]["mean_per_dispatch"] * 1024
+        ent.update(hbm_bytes_per_launch=f + w, fetch_bytes=f, write_bytes=w, traffic_from="profiles/%s_rocprof_summary.json" % tag.replace("default", "pmc"))
+        hashes.add(p.get("source_hash"))
+        steps = n * ent["steps_per_launch"]
+        print("traffic per env-step: %.1f B (fetch %.1f, write %.1f)" % ((f + w) / steps, f / steps, w / steps))
+    cur["kernels"]["%s/%s/%d" % (short(t["kernel"]), conf, n)] = ent
+if len(hashes) == 1:
+    cur["source_hash"] = hashes.pop()
+else:
+    print("WARNING: the summaries come from different libraries:", hashes)
+json.dump(cur, open(os.path.join(dst, "current.json"), "w"), indent=1)
+print("wrote profiles/current.json for library", str(cur["source_hash"])[:12])
