@@ -186,9 +186,10 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
  * does per rollout fragment (T consecutive BaseDroneEnv.vector_step calls, BaseDroneEnv.py:259-294; 1024-step fragments,
  * train_RMA.py:63).  For fragments whose actions are already on the device (replays, or a policy that wrote the whole
  * fragment).  Two ways of running it, chosen per env configuration (qd_fragment_kernel_name tells which):
- *   - ONE persistent launch (k_rollout_coop, csrc/qd_rollout_coop.hip) for train_PPO.py / train_RMA.py's configuration
- *     (load model, LocalFrameRPYParamsEnv, distance_energy_reward) up to QD_COOP_MAX_ENVS envs: four wavefronts per 64 envs keep
- *     the state on their CU for all T steps, only actions come in and rows / rewards / flags go out.  Same results as T x
+ *   - ONE persistent launch (k_rollout_coop, csrc/qd_rollout_coop.hip) for the load model with skip_steps = 1 (every observation
+ *     variant and reward; compile-time specialisations for train_PPO.py / train_RMA.py's and train_LSTM.py's configurations), at
+ *     every batch size: four wavefronts per 64 envs keep the state on their CU for all T steps, only actions come in and rows /
+ *     rewards / flags go out.  Same results as T x
  *     qd_step up to the rounding of two compilations of the same arithmetic (the truncation flags exactly; bit-identical to
  *     itself whatever the batch size and wherever a run is cut into fragments).  QD_OPT_PERSISTENT_FRAGMENTS = 0 (qd_set_option)
  *     or QD_PERSISTENT=0 in the environment selects the other way;
@@ -205,7 +206,7 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
 enum { QD_OPT_PERSISTENT_FRAGMENTS = 0, QD_OPT_COUNT };
 int qd_set_option(qd_env* env, int option, int value);
 /* The kernel that a qd_step / a qd_step_fragment of this env launches right now (static strings; the variant selector's own
- * answer, for benchmark lines and profiles: "qd::k_step_coop<1>", "qd::k_rollout_coop<1>", ...). */
+ * answer, for benchmark lines and profiles: "qd::k_step_coop<1>", "qd::k_rollout_coop<1,2>", ...). */
 const char* qd_step_kernel_name(const qd_env* env);
 const char* qd_fragment_kernel_name(const qd_env* env);
 /* How the in-kernel resets (auto_reset) since qd_init got their new state: counters[0] = served by the reset pool (an entry

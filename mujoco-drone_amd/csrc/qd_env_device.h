@@ -586,8 +586,8 @@ __device__ __forceinline__ void coop_obs_part(const KArgs& a, int i, int lane, c
     if ((((MASK >> k) & 1u) != 0u) == FRAME) row[k] = o[k];
 }
 
-// qd_rollout_coop.hip: T steps of the training configuration (SPEC_RMA, load model) in ONE launch, four wavefronts per 64 envs.
-// `k` as qd_step would pass it (main_blocks is set by the launcher).
-hipError_t launch_rollout_coop(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
+// qd_rollout_coop.hip: T steps of the load model (SPEC_RMA, SPEC_LSTM or SPEC_GENERIC_FS1: one substep per step) in ONE launch,
+// four wavefronts per 64 envs.  `k` as qd_step would pass it (main_blocks is set by the launcher).
+hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 
 }  // namespace qd

@@ -1361,8 +1361,17 @@ static int qd_persistent_max_envs() {
   static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS"); return e ? atoi(e) : 0x7fffffff; }();
   return v;
 }
+// (the sensor-carrying / run-time-dispatched instantiations spill under the two-workgroups-per-CU register cap and lose to the
+// 256-thread per-step kernel at very large batches: config 5 at 2^20 envs 118 against 105 us per step; QD_PERSISTENT_MAX_ENVS_OTHER)
+static int qd_persistent_max_envs_other() {
+  static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS_OTHER"); return e ? atoi(e) : 262144; }();
+  return v;
+}
 static bool qd_fragment_is_persistent(const qd_env* env) {
-  return qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && env->load && env->spec == SPEC_RMA && env->ka.n <= qd_persistent_max_envs();
+  if (!(qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && env->load)) return false;
+  if (env->spec == SPEC_RMA) return env->ka.n <= qd_persistent_max_envs();
+  if (env->spec == SPEC_LSTM || env->spec == SPEC_GENERIC_FS1) return env->ka.n <= qd_persistent_max_envs() && env->ka.n <= qd_persistent_max_envs_other();
+  return false;
 }
 
 int qd_set_option(qd_env* env, int option, int value) {
@@ -1386,7 +1395,11 @@ const char* qd_step_kernel_name(const qd_env* env) {
 }
 const char* qd_fragment_kernel_name(const qd_env* env) {
   if (!env) return "";
-  return qd_fragment_is_persistent(env) ? "qd::k_rollout_coop<1>" : qd_step_kernel_name(env);
+  if (!qd_fragment_is_persistent(env)) return qd_step_kernel_name(env);
+  const bool two = env->ka.n > 256 * 64;
+  return env->spec == SPEC_RMA ? "qd::k_rollout_coop<1,2>"
+       : env->spec == SPEC_LSTM ? (two ? "qd::k_rollout_coop<2,2>" : "qd::k_rollout_coop<2,1>")
+                                : (two ? "qd::k_rollout_coop<4,2>" : "qd::k_rollout_coop<4,1>");
 }
 
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
@@ -1397,7 +1410,7 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
   const int n = env->ka.n;
   const size_t D = (size_t)env->D;
   if (qd_fragment_is_persistent(env)) {
-    QD_HIP(launch_rollout_coop(env->ka, T, actions, obs, reward, truncated, S(stream)));
+    QD_HIP(launch_rollout_coop(env->ka, env->spec, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
   qd_env::Frag* fr = nullptr;
@@ -1488,7 +1501,7 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
     return QD_OK;
   }
   if (qd_fragment_is_persistent(env)) {
-    QD_HIP(launch_rollout_coop(k, T, actions, obs, reward, truncated, S(stream)));
+    QD_HIP(launch_rollout_coop(k, env->spec, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
   const dim3 grid(blocks64(k.n)), block(64);

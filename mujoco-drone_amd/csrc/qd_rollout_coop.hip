@@ -48,7 +48,10 @@ struct RcLds {
   float4 pre[6][64];      // A -> D: the state after the step and BEFORE the reset, truncated lanes only (the reward is of this state)
   uint4 info[64];         // A -> C, D: (bit 0 truncated | bit 1 reset), episode counter of s_{t+1}, num_steps after the step, -
   float4 nxt[2][5][64];   // the reset pool: slot e & 1 = entry of episode e, planes as in the arena (tag plane last)
-  float tile[64 * 24];    // wave D: the group's observation rows, row-major like the global span
+  float4 acc[64];         // A -> D: the accelerometer reading of the previous round (sensor-reading observation variants)
+  float4 acc2[64];        // A -> D: the reading at the state the fragment ends in (the extra half round)
+  float tile[2][64 * QD_MAX_OBS];   // wave D: the group's observation rows, row-major like the global span; two, because the rows
+                                    // of a sensor-reading variant are completed and written out a round after they are built
 };
 
 __device__ __forceinline__ void rc_put_state(float4 (*st)[64], int lane, const State<float>& s) {
@@ -106,13 +109,48 @@ __device__ unsigned long long qd_rcstamps[64 * 4 * 16];
 #define RC_STAMP(k)
 #endif
 
-template <int SPEC>
-// (two workgroups per CU: <= 256 registers per wave cost nothing here -- 251 used, no scratch -- and double the envs in flight at large batches)
-__global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
+// where the three accelerometer values sit in the observation row of a variant that carries them (-1: it does not)
+__device__ __forceinline__ int rc_acc_slot(int kind) {
+  switch (kind) {
+    case OBS_RAW: return 16;
+    case OBS_FULLSTATE: case OBS_PRY_ACC: case OBS_PRY_ACC_NOPEND: return 12;
+    case OBS_FULLSTATE_ZVEC: return 13;
+    case OBS_PRY_ACC_PARAMS: return 14;
+    default: return -1;
+  }
+}
+// the accelerometer reading of a step from its factor and right-hand side (what k_step_coop's phase 3 computes)
+__device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rhs<double>& r, const M3<float>& R, V3<float> w0) {
+  Accel<float> ex;
+  V3<double> a0ex;
+  finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+  const float g = float(Const::gravity);
+  return accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                       mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+}
+
+// SPEC_RMA (train_PPO.py / train_RMA.py), SPEC_LSTM (train_LSTM.py) or SPEC_GENERIC_FS1 (any observation / reward of the load
+// model, dispatched at run time in wave D), all with skip_steps = 1.
+//
+// Observation variants that carry the accelerometer (`sens`): the reading in the row of step k is the one mj_step computed in
+// that step, at the state the step STARTED from (quirk C-6) -- for the solver wave that is the explicit solve of round k, which
+// it evaluates at the start of round k + 1 (its phase 1 has slack) and publishes as L.acc.  The row of a lane that was reset
+// in step k instead carries mj_forward's reading at the NEW state with the activations that survived the reset (set_state ->
+// mj_forward, mujoco_vecenv.py:396-402): exactly the reading round k + 1 computes anyway.  So the sensor entries of row k are
+// final one round later than the rest of it; wave D builds the row into one of two LDS tiles, and patches the three values in
+// and writes the tile out a round later.  The fragment's last row needs the reading at s_T: one extra half round (phase 1 and
+// the explicit solve, no integration).  No affine sensor form in the pool, no forward dynamics re-run in a truncating lane.
+// OCC: workgroups per CU the register budget allows.  Two (<= 256 registers per wave) double the envs in flight at large batches
+// and cost SPEC_RMA nothing (251 registers, no scratch); the sensor-carrying and run-time-dispatched instantiations spill a
+// dozen registers under that cap, so batches that leave the second slot empty anyway (<= 16384 envs = 256 workgroups) run
+// their OCC = 1 instantiation.
+template <int SPEC, int OCC>
+__global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
                                                              float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
-  static_assert(SPEC == SPEC_RMA, "persistent fragment kernel: LocalFrameRPYParamsEnv + distance_energy_reward on the load model");
-  constexpr int D = spec_obs_dim<SPEC>();
-  constexpr int KIND = (int)OBS_RPY_PARAMS;
+  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM || SPEC == SPEC_GENERIC_FS1, "persistent fragment kernel: the load model, one substep per step");
+  const int D = spec_runtime<SPEC>() ? a.D : spec_obs_dim<SPEC>();
+  const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
+  const int rounds = T + (sens ? 1 : 0);
   __shared__ RcLds L;
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -141,18 +179,24 @@ __global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, 
     Factor<double> f;
     Rhs<double> r;
     M3<float> R;
-    V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
-    for (int t = 0; t < T; t++) {
+    V3<float> w0 = mk<float>(0.f, 0.f, 0.f), acc_last = mk<float>(0.f, 0.f, 0.f);
+    bool rst_last = false;
+    for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
+      const bool half = t == T;   // `sens` only: the forward dynamics at s_T for the last row's sensor entries, nothing integrated
       const float4 action = act_next;
       if (t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       // ---------------------------------------------------------- phase 1
+      if (sens && t >= 1) {   // the reading of round t - 1, from that round's factor and right-hand side (before they are replaced)
+        acc_last = rc_sensor(f, r, R, w0);
+        L.acc[lane] = make_float4(acc_last.x, acc_last.y, acc_last.z, 0.f);
+      }
       const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
       f = mass_factor(e.M, tg, a.h);
-      {
-        const float c0 = qclamp(0.1f + 0.9f * action.x, 0.f, 1.f), c1 = qclamp(0.1f + 0.9f * action.y, 0.f, 1.f);
-        const float c2 = qclamp(0.1f + 0.9f * action.z, 0.f, 1.f), c3 = qclamp(0.1f + 0.9f * action.w, 0.f, 1.f);
-        integrate_act(e.M, e.s, c0, c1, c2, c3, a.h);
+      if (!half) {
+        float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
+        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
       }
       rc_ref(a, i, e.num_steps, ref0, e.ref);
       // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
@@ -181,66 +225,72 @@ __global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, 
         }
         r = reduce_rhs(f, ap, in);
       }
-      Accel<float> im;
-      V3<double> a0im;
-      finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
-      im.lin = mul(R, cvt<float>(a0im));
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
-      integrate_motion<float, true>(e.s, im, a.h);
-      e.flags &= ~FLAG_ACC_STALE;
-      e.num_steps += 1;
-      const int steps_post = e.num_steps;
-      bool tr;
-      {  // default_termination_fcn on the position alone (the same test truncated() makes on the state vector)
-        const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
-        tr = !(qsqrt(dx * dx + dy * dy + dz * dz) <= a.max_distance) || e.num_steps >= a.max_steps;
-      }
-      const bool rst = a.auto_reset && tr;
-      if (rst) {
-        rc_put_state(L.pre, lane, e.s);
-        State<float> ns;   // the new episode's state; the activations carry over (reset_bookkeeping)
-        bool taken = false;
-        if (a.use_pool) {
-          const int sl = (int)(e.episode & 1u);
-          const float4 nx4 = L.nxt[sl][4][lane];
-          taken = rc_entry_valid(nx4, e.episode);
-          if (taken) {
-            const float4 p = L.nxt[sl][0][lane], q = L.nxt[sl][1][lane], v = L.nxt[sl][2][lane], w = L.nxt[sl][3][lane];
-            ns.px = p.x; ns.py = p.y; ns.pz = p.z; ns.th1 = p.w;
-            ns.qw = q.x; ns.qx = q.y; ns.qy = q.z; ns.qz = q.w;
-            ns.vx = v.x; ns.vy = v.y; ns.vz = v.z; ns.th2 = v.w;
-            ns.wx = w.x; ns.wy = w.y; ns.wz = w.z; ns.thd1 = w.w;
-            ns.thd2 = nx4.x;
-          }
+      if (!half) {
+        Accel<float> im;
+        V3<double> a0im;
+        finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+        im.lin = mul(R, cvt<float>(a0im));
+        integrate_motion<float, true>(e.s, im, a.h);
+        e.flags &= ~FLAG_ACC_STALE;
+        e.num_steps += 1;
+        const int steps_post = e.num_steps;
+        bool tr;
+        {  // default_termination_fcn / SimpleDrone's rule on the position alone (the tests truncated() / env_step make on the state vector)
+          const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+          const float dist = qsqrt(dx * dx + dy * dy + dz * dz);
+          tr = spec_term<SPEC>(a) == QD_TERM_SIMPLE ? dist > 0.5f : (!(dist <= a.max_distance) || e.num_steps >= a.max_steps);
         }
-        if (!taken) sample_episode<true>(a, i, e.episode, ns);
-        ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
-        e.s = ns;
-        reset_bookkeeping(e.s, e.episode, e.num_steps);
-        e.flags |= FLAG_ACC_STALE;   // the row does not carry the sensor: recomputed by the next step, or by a getter that runs first
-        if (a.use_pool && live) pool_count(a, taken);
+        const bool rst = a.auto_reset && tr;
+        if (rst) {
+          rc_put_state(L.pre, lane, e.s);
+          State<float> ns;   // the new episode's state; the activations carry over (reset_bookkeeping)
+          bool taken = false;
+          if (a.use_pool) {
+            const int sl = (int)(e.episode & 1u);
+            const float4 nx4 = L.nxt[sl][4][lane];
+            taken = rc_entry_valid(nx4, e.episode);
+            if (taken) {
+              const float4 p = L.nxt[sl][0][lane], q = L.nxt[sl][1][lane], v = L.nxt[sl][2][lane], w = L.nxt[sl][3][lane];
+              ns.px = p.x; ns.py = p.y; ns.pz = p.z; ns.th1 = p.w;
+              ns.qw = q.x; ns.qx = q.y; ns.qy = q.z; ns.qz = q.w;
+              ns.vx = v.x; ns.vy = v.y; ns.vz = v.z; ns.th2 = v.w;
+              ns.wx = w.x; ns.wy = w.y; ns.wz = w.z; ns.thd1 = w.w;
+              ns.thd2 = nx4.x;
+            }
+          }
+          if (!taken) sample_episode<true>(a, i, e.episode, ns);
+          ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
+          e.s = ns;
+          reset_bookkeeping(e.s, e.episode, e.num_steps);
+          // without the sensor in the row the stored reading is only marked stale (the next step, or a getter that runs first,
+          // recomputes it); with it, the next round's reading takes its place (below)
+          if (!sens) e.flags |= FLAG_ACC_STALE;
+          if (a.use_pool && live) pool_count(a, taken);
+        }
+        rst_last = rst;
+        rc_put_state(L.st, lane, e.s);
+        L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
+      } else {
+        // the reading at s_T: the sensor entries of the last row where the last step reset the lane, and what mj_forward leaves
+        const V3<float> accT = rc_sensor(f, r, R, w0);
+        L.acc2[lane] = make_float4(accT.x, accT.y, accT.z, 0.f);
+        if (rst_last) acc_last = accT;
       }
-      rc_put_state(L.st, lane, e.s);
-      L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
       RC_STAMP(3);
       coop_barrier();   // 2
       RC_STAMP(4);
     }
     // the fragment's last step leaves what a per-step launch leaves: the state, and the accelerometer reading of that step
-    // (quirk C-6: the reading of the state the step STARTED from), also where a reset marked it stale
+    // (quirk C-6: the reading of the state the step STARTED from; where a reset replaced or invalidated it, see above)
     if (live) {
-      Accel<float> ex;
-      V3<double> a0ex;
-      finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
-      const float g = float(Const::gravity);
-      e.acc = accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
-                            mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+      e.acc = sens ? acc_last : rc_sensor(f, r, R, w0);
       store_env(a, i, e);
     }
   } else if (role == 1) {
     // ================================================================ wave B: thrust + drag on the three bodies
     coop_barrier();   // P
-    for (int t = 0; t < T; t++) {
+    for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
       State<float> s;
       rc_get_state(L.st, lane, s);
@@ -284,7 +334,7 @@ __global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, 
     jns.px = jns.py = jns.pz = jns.qw = jns.qx = jns.qy = jns.qz = jns.th1 = jns.th2 = 0.f;
     jns.vx = jns.vy = jns.vz = jns.wx = jns.wy = jns.wz = jns.thd1 = jns.thd2 = jns.a0 = jns.a1 = jns.a2 = jns.a3 = 0.f;
     int jphase = 0;
-    for (int t = 0; t < T; t++) {
+    for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
       if (jphase == JOB_DONE) {   // commit: wave A is in its phase 1 and does not read the pool
         if (jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
@@ -332,7 +382,8 @@ __global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, 
       RC_STAMP(4);
     }
     // hand the pool back to the arena as the per-step kernels expect it: the entry of every env's current counter and of the
-    // one after it, complete (what the chunked job had not finished is sampled here, once per fragment)
+    // one after it, complete (what the chunked job had not finished is sampled here, once per fragment); entries are "state
+    // only" (POOL_STATE): a per-step kernel of a sensor-reading configuration adds the second stage itself
     if (pool) {
       if (jphase == JOB_DONE && jx != NONE) pool_put_lds(L.nxt[jx & 1u], lane, jx, jns);
       const uint32_t episode = L.info[lane].y;
@@ -354,69 +405,107 @@ __global__ __launch_bounds__(RC_THREADS, 2) void k_rollout_coop(KArgs a, int T, 
       }
     }
   } else {
-    // ================================================================ wave D: observation rows, rewards, flags -- one step behind
+    // ================================================================ wave D: observation rows, rewards, flags -- one round behind
+    // (the sensor entries of a row and its write-out: two rounds behind, see the head of the kernel)
     float4 act_prev = actions4[il];   // the action of step t - 1 when iteration t uses it
     coop_barrier();   // P
-    for (int t = 0; t <= T; t++) {
+    const int acc_at = sens ? rc_acc_slot(spec_obs<SPEC>(a)) : -1;
+    const int rows = min(64, n - base_env);
+    V3<float> acc_prev = mk<float>(0.f, 0.f, 0.f);
+    bool rst_prev = false;
+    for (int t = 0; t <= rounds; t++) {
       RC_STAMP(0);
       float sv[33];
       M3<float> Rq;
       float ref_t[4];
       uint4 info = make_uint4(0u, 0u, 0u, 0u);
       bool rst = false;
-      if (t >= 1) {
+      const bool row_now = t >= 1 && t <= T;   // the row of step t - 1 is the observation of s_t
+      float* tile_now = L.tile[(t - 1) & 1];
+      if (row_now) {
         info = L.info[lane];
         rst = (info.x & 2u) != 0u;
-        State<float> s;
-        rc_get_state(L.st, lane, s);
+        EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
+        rc_get_state(L.st, lane, ed.s);
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
-        float refo[4] = {ref_t[0], ref_t[1], ref_t[2], ref_t[3]};
-        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, refo);   // a new episode's first row
-        float o[QD_MAX_OBS];
-        drone_state<float, true>(s, mk<float>(0.f, 0.f, 0.f), refo, e.par, sv, &Rq);
-        observe<float, 33, KIND>(sv, refo, o, &Rq);
-        float* row = L.tile + lane * D;
-#pragma unroll
-        for (int k = 0; k < D; k++) row[k] = o[k];
+        ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
+        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
+        drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
+        write_obs_row<true, SPEC>(a, ed, sv, &Rq, tile_now + lane * D);
       }
       RC_STAMP(1);
-      if (t < T) coop_barrier();   // 1
+      if (t < rounds) coop_barrier();   // 1
       RC_STAMP(2);
-      if (t >= 1) {
+      V3<float> acc_new = mk<float>(0.f, 0.f, 0.f);
+      if (sens && t >= 1) {   // the reading of round t - 1 (wave A's phase 1 of this round); in the last iteration the one at s_T
+        const float4 x = (t == rounds) ? L.acc2[lane] : L.acc[lane];
+        acc_new = mk<float>(x.x, x.y, x.z);
+      }
+      if (row_now) {
         const float act4[4] = {act_prev.x, act_prev.y, act_prev.z, act_prev.w};
-        float rw = reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
+        const bool simple = spec_term<SPEC>(a) == QD_TERM_SIMPLE;
+        float rw;
+        if (simple) {   // SimpleDrone.step's reward on this model (env_step: 0.1 - |pos - ref|)
+          const float dx = sv[0] - ref_t[0], dy = sv[1] - ref_t[1], dz = sv[2] - ref_t[2];
+          rw = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
+        } else {
+          rw = reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
+        }
         if (__any(rst ? 1 : 0)) {   // the reward of a truncated lane is of the state BEFORE its reset
           State<float> p;
           rc_get_state(L.pre, lane, p);
           float sv2[33];
           M3<float> Rq2;
           drone_state<float, true>(p, mk<float>(0.f, 0.f, 0.f), ref_t, e.par, sv2, &Rq2);
-          const float rw2 = reward<float>(spec_reward<SPEC>(a), sv2, act4, (int)info.z, ref_t, a.max_distance, &Rq2);
+          float rw2;
+          if (simple) {
+            const float dx = sv2[0] - ref_t[0], dy = sv2[1] - ref_t[1], dz = sv2[2] - ref_t[2];
+            rw2 = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
+          } else {
+            rw2 = reward<float>(spec_reward<SPEC>(a), sv2, act4, (int)info.z, ref_t, a.max_distance, &Rq2);
+          }
           if (rst) rw = rw2;
         }
         if (live) {
           __builtin_nontemporal_store(rw, reward_out + (size_t)(t - 1) * n + i);
           __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc_out + (size_t)(t - 1) * n + i);
         }
-        flush_obs_any<SPEC>(L.tile, obs + ((size_t)(t - 1) * n + base_env) * D, min(64, n - base_env), D);
+        if (!sens) flush_obs_any<SPEC>(tile_now, obs + ((size_t)(t - 1) * n + base_env) * D, rows, D);
       }
+      if (sens && t >= 2) {   // row t - 2: its sensor entries are final now
+        float* tile_then = L.tile[t & 1];
+        const V3<float> af = rst_prev ? acc_new : acc_prev;
+        float* row = tile_then + lane * D + acc_at;
+        row[0] = af.x; row[1] = af.y; row[2] = af.z;
+        __builtin_amdgcn_wave_barrier();
+        flush_obs_any<SPEC>(tile_then, obs + ((size_t)(t - 2) * n + base_env) * D, rows, D);
+      }
+      acc_prev = acc_new;
+      rst_prev = rst;
       if (t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
       RC_STAMP(3);
-      if (t < T) coop_barrier();   // 2
+      if (t < rounds) coop_barrier();   // 2
       RC_STAMP(4);
     }
   }
 }
 
-hipError_t launch_rollout_coop(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
+hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
   KArgs kk = k;
   kk.main_blocks = (k.n + 63) / 64;
   // the workgroup's own sampler costs no extra workgroups, so the pool is on at every batch size (qd_create switches the ARENA
   // pool off from 32768 envs, where sampler workgroups no longer find idle SIMDs); entries are a pure function of
   // (seed, env, episode), so the per-step kernels can use or ignore what this kernel leaves in the arena
   kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED) ? 1 : 0;
+  const dim3 grid(kk.main_blocks), block(RC_THREADS);
   (void)hipGetLastError();
-  hipLaunchKernelGGL((k_rollout_coop<SPEC_RMA>), dim3(kk.main_blocks), dim3(RC_THREADS), 0, stream, kk, T, actions, obs, reward, trunc);
+  const bool two = kk.main_blocks > 256;   // more workgroups than CUs: the second slot per CU is worth its register cap
+#define RC_LAUNCH(SPECV, OCCV) hipLaunchKernelGGL((k_rollout_coop<SPECV, OCCV>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc)
+  if (spec == SPEC_RMA) RC_LAUNCH(SPEC_RMA, 2);
+  else if (spec == SPEC_LSTM) { if (two) RC_LAUNCH(SPEC_LSTM, 2); else RC_LAUNCH(SPEC_LSTM, 1); }
+  else if (spec == SPEC_GENERIC_FS1) { if (two) RC_LAUNCH(SPEC_GENERIC_FS1, 2); else RC_LAUNCH(SPEC_GENERIC_FS1, 1); }
+  else return hipErrorInvalidValue;
+#undef RC_LAUNCH
   return hipGetLastError();
 }
 

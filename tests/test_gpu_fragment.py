@@ -275,3 +275,147 @@ def test_fragment_buffers_are_validated(qd):
         env.step_fragment(acts, O, R.cpu(), Tr)
     with pytest.raises(ValueError):
         env.step_fragment(acts[:, :, :3], O, R, Tr)
+
+
+# ------------------------------------------------------------------ the other instantiations: train_LSTM.py's configuration, run-time dispatch
+def _close_rows(O, o, acc_at, what, tol_acc=3e-3, tol=None):
+    """rows of a sensor-carrying variant: everything at OBS_ATOL except the three accelerometer entries (the reading amplifies
+    rate differences by 1 / inertia; and a reset row's reading comes from the pool's affine form in the per-step kernel, from the
+    next step's own solve here)"""
+    d = _heading_safe_absdiff(O, o)
+    if acc_at is not None:
+        da = float(d[..., acc_at:acc_at + 3].max())
+        d[..., acc_at:acc_at + 3] = 0
+        assert da <= tol_acc, "%s: accelerometer entries %.3e" % (what, da)
+    assert float(d.max()) <= (tol or 5 * OBS_ATOL), "%s: %.3e" % (what, float(d.max()))
+
+
+@pytest.mark.parametrize("n", [500, 20000])
+def test_config5_fragment_equals_per_step_kernel(qd, n):
+    """BASELINE config 5 (train_LSTM.py: LocalFrameFullStateEnv, distance_energy_reward_pendulum_en4, circle waypoint per env)
+    through k_rollout_coop<SPEC_LSTM>: the row carries the accelerometer, so rows are completed a round late and a reset row
+    takes the next round's reading.  Against the single-wave per-step kernel (k_step<true,64,2>, monolithic forward dynamics):
+    flags exactly, values to rounding; both register-budget instantiations (<= 16384 envs / above)"""
+    import bench
+    T = 48
+    e1, _ = bench.make_env("config5", n, 42, "cuda:0")
+    e2, _ = bench.make_env("config5", n, 42, "cuda:0")
+    e1.vector_reset_tensor(); e2.vector_reset_tensor()
+    assert "k_rollout_coop<2" in e1._dev.fragment_kernel_name()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    resets = 0
+    for rep in range(2):
+        # two float32 implementations of a chaotic system (state_difficulty 0.8, episodes of hundreds of steps, the monolithic
+        # forward dynamics against its three pieces): they drift apart at ~1e-6 per step early on, 1.5e-4 after 67 steps.  Each
+        # 48-step fragment therefore starts from the same arena; the bound that matters is the float64 oracle's (below)
+        e2._dev.arena.copy_(e1._dev.arena)
+        acts = torch.rand((T, n, 4), generator=g, device="cuda")
+        O, R, Tr = _bufs(T, n, 23)
+        e1.step_fragment_tensor(acts, O, R, Tr)
+        for t in range(T):
+            o, r, tr = e2.vector_step_tensor(acts[t])
+            assert torch.equal(Tr[t], tr), (rep, t)
+            _close_rows(O[t], o, 12, "rep %d t %d" % (rep, t), tol=3e-4)
+            assert float((R[t] - r).abs().max()) <= 1e-3, (rep, t, float((R[t] - r).abs().max()))
+        resets += int(Tr.sum())
+        for x, y, name in zip(e1._dev.get_state(), e2._dev.get_state(), ("qpos", "qvel", "act", "sensordata", "num_steps")):
+            tol = 0 if name == "num_steps" else (3e-3 if name == "sensordata" else 3e-4)
+            assert float((x.float() - y.float()).abs().max()) <= tol, (name, float((x.float() - y.float()).abs().max()))
+    assert resets > 0.002 * n * T          # state_difficulty 0.8: resets do happen inside 96 steps
+
+
+def test_config5_fragment_is_batch_and_cut_invariant(qd):
+    """the sensor pipeline (rows a round late, the extra half round at the end of every fragment) must not make results depend
+    on where a run is cut: 40 steps at once == 13 + 1 + 26, and 20000 envs == the first 64 alone... except that config 5's
+    waypoint phase depends on the batch size (2 pi i / N), so batch invariance is checked on a static-reference variant"""
+    L, T = qd._lib, 40
+    mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, obs="LocalFrameFullStateEnv", reward="distance_energy_reward_pendulum_en4",
+                                             start=1, random_params=0, auto_reset=1, max_steps=7, seed=13, sdiff=0.8))
+    big, small, cut = mk(20000), mk(64), mk(20000)
+    for e in (big, small, cut):
+        e.reset()
+    assert "k_rollout_coop<2,2>" in big.fragment_kernel_name() and "k_rollout_coop<2,1>" in small.fragment_kernel_name()
+    acts = torch.rand((T, 20000, 4), device="cuda")
+    Ob, Rb, Tb = _bufs(T, 20000, 23)
+    big.step_fragment(acts, Ob, Rb, Tb)
+    Oc, Rc, Tc = _bufs(T, 20000, 23)
+    for lo, hi in ((0, 13), (13, 14), (14, 40)):
+        cut.step_fragment(acts[lo:hi], Oc[lo:hi], Rc[lo:hi], Tc[lo:hi])
+    assert torch.equal(Tb, Tc) and torch.equal(Rb, Rc)
+    assert torch.equal(Ob, Oc), "cuts: max |d obs| %.3e" % float((Ob - Oc).abs().max())
+    for x, y in zip(big.get_state(), cut.get_state()):
+        assert torch.equal(x, y)
+    # the two register budgets are two compilations: rounding-level agreement, flags exact
+    Os, Rs, Ts = _bufs(T, 64, 23)
+    small.step_fragment(acts[:, :64].contiguous(), Os, Rs, Ts)
+    assert torch.equal(Tb[:, :64], Ts)
+    _close_rows(Ob[:, :64], Os, 12, "OCC 2 vs OCC 1")
+
+
+@pytest.mark.parametrize("obs,reward,acc_at", [("BaseDroneEnv", "default_reward_fcn", 16),
+                                               ("LocalFramePRYaccParamsEnv", "reward_2", 14),
+                                               ("LocalFrameFullStateZvecEnv", "distance_energy_reward_pendulum_en2", 13),
+                                               ("GlobalFrameRPYEnv", "reward_pendulumDistHeading", None),
+                                               ("LocalFrameRmParamsEnv", "reward_3", None)])
+def test_generic_fragment_equals_per_step_kernel(qd, obs, reward, acc_at):
+    """k_rollout_coop<SPEC_GENERIC_FS1>: any observation variant / reward of the load model, dispatched at run time in the epilogue
+    wave, with and without the accelerometer in the row; against the per-step kernel k_step<true,64,4>"""
+    L, n, T = qd._lib, 700, 30
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs=obs, reward=reward, start=1, random_params=1, auto_reset=1,
+                                             max_steps=8, seed=17))
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    assert "k_rollout_coop<4" in a.fragment_kernel_name(), a.fragment_kernel_name()
+    D = a.D
+    g = torch.Generator(device="cuda").manual_seed(2)
+    for rep in range(2):
+        acts = torch.rand((T, n, 4), generator=g, device="cuda")
+        O, R, Tr = _bufs(T, n, D)
+        a.step_fragment(acts, O, R, Tr)
+        for t in range(T):
+            o, r, tr = b.step(acts[t])
+            assert torch.equal(Tr[t], tr), (rep, t)
+            d = (O[t] - o).abs()
+            if obs != "BaseDroneEnv":
+                d[:, 5] = torch.minimum(d[:, 5], (d[:, 5] - 2 * np.pi).abs())
+            if acc_at is not None:
+                assert float(d[:, acc_at:acc_at + 3].max()) <= 3e-3, (rep, t, float(d[:, acc_at:acc_at + 3].max()))
+                d[:, acc_at:acc_at + 3] = 0
+            assert float(d.max()) <= 1e-4, (rep, t, float(d.max()))
+            assert float((R[t] - r).abs().max()) <= 5e-4 * max(1.0, float(r.abs().max())), (rep, t)
+    assert int(Tr.sum()) > 0
+
+
+def test_config5_full_size_fragment_vs_oracle_200_steps(qd, orc):
+    """BASELINE config 5 at its quoted size THROUGH THE PERSISTENT KERNEL: all 8192 envs, 200 steps as four 50-step fragments against
+    the float64 oracle (state_difficulty 0.8 starts, U[0,1) rotor commands, no resets): state <= 1e-4 at step 200, the
+    accelerometer the rows carry, and every step's rows against the oracle's observation of its own state"""
+    import bench
+    n, steps, F, L = 8192, 200, 50, qd._lib
+    env, _ = bench.make_env("config5", n, 42, "cuda:0", auto_reset=False)
+    env.vector_reset_tensor()
+    assert env._dev.fragment_kernel_name() == "qd::k_rollout_coop<2,1>"
+    q0, v0, a0, _, _ = [x.cpu().numpy().astype(np.float64) for x in env._dev.get_state()]
+    raw = env._dev.get_params().cpu().numpy()
+    ob = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameFullStateEnv"), L.REWARD_KINDS.index("distance_energy_reward_pendulum_en4"),
+                   0.01, 1, 1, (0, 0, 15, 0), 1e9, 10 ** 6)
+    ob.qpos[:], ob.qvel[:], ob.act[:] = q0, v0, a0
+    g = torch.Generator(device="cuda").manual_seed(11)
+    O, R, Tr = _bufs(F, n, 23)
+    div = Divergence(True)
+    worst_acc = 0.0
+    for f in range(steps // F):
+        acts = torch.rand((F, n, 4), generator=g, device="cuda")
+        env.step_fragment_tensor(acts, O, R, Tr)
+        ah, Oh = acts.cpu().numpy().astype(np.float64), O.cpu().numpy().astype(np.float64)
+        for t in range(F):
+            ob.step(ah[t], threads=8)
+            # the row's sensor entries are the reading mj_step computed in this step (quirk C-6), which the oracle keeps too
+            worst_acc = max(worst_acc, float(np.max(np.abs(Oh[t][:, 12:15] - ob.sensor) / np.maximum(1.0, np.abs(ob.sensor)))))
+        gq, gv, ga, gs, _ = [x.cpu().numpy().astype(np.float64) for x in env._dev.get_state()]
+        div.update(dict(qpos=gq, qvel=gv, act=ga), dict(qpos=ob.qpos, qvel=ob.qvel, act=ob.act))
+    print(div.table("config 5 through k_rollout_coop<SPEC_LSTM>, 8192 envs, 200 steps vs the float64 oracle"))
+    print("accelerometer entries of the rows vs the oracle's sensor, max relative over 200 steps x 8192 envs: %.3e" % worst_acc)
+    assert div.max("mixed") < 1e-4 and div.max("rel") < 1e-4
+    assert worst_acc < 2e-3
+    np.testing.assert_allclose(gs, ob.sensor, rtol=2e-4, atol=2e-3)

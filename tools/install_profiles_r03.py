@@ -38,7 +38,7 @@ for f in os.listdir(src):
 
 
 def short(name):     # "void qd::k_rollout_coop<1>(qd::KArgs, ...)" -> "qd::k_rollout_coop<1>"
-    name = name.split("(")[0]
+    name = name.split("(")[0].replace(", ", ",")
     return name[5:] if name.startswith("void ") else name
 
 
