@@ -248,7 +248,9 @@ def launch_ranks(n_ranks, argv):
     return 0
 
 
-PERSISTENT_OWN_BYTES = 109   # what k_rollout_coop itself moves per env-step: action R 16 + obs W 88 + reward W 4 + truncated W 1
+def persistent_own_bytes(D):
+    """what a persistent fragment kernel itself moves per env-step: action R 16 + row W 4 D + reward W 4 + truncated W 1 (config 3: 109)"""
+    return 16 + 4 * D + 4 + 1
 
 
 def launch_text(env, K, timed_runs):
@@ -256,8 +258,8 @@ def launch_text(env, K, timed_runs):
     if env is None:
         return "dry run: no launches"
     name = env._dev.fragment_kernel_name()
-    if "k_rollout_coop" in name:
-        return ("ONE persistent kernel launch per run of steps (%s, four wavefronts per 64 envs keep the state on their CU for the whole run), "
+    if "k_rollout" in name:
+        return ("ONE persistent kernel launch per run of steps (%s: the envs' state stays on their CU -- in registers / LDS -- for the whole run), "
                 "issued through qd_step_fragment (C ABI): the %d timed steps went out as %d launch(es) of %s steps; the per-step-launch "
                 "figure of the same workload is extras.per_step_launch_env_steps_per_s" % (name, K, len(timed_runs), runs))
     return ("one step-kernel launch per step (%s), issued through qd_step_fragment (C ABI), one call per run of steps inside a "
@@ -507,7 +509,7 @@ def main():
         # kernel one step (duration incl. the inter-kernel boundary, as rocprofv3's trace reports back-to-back dispatches).
         # achieved = SURVEY 8d's algorithmic bytes per env-step x the env-steps one launch processes / kernel_us.
         kname = env._dev.fragment_kernel_name()
-        persistent = "k_rollout_coop" in kname
+        persistent = "k_rollout" in kname
         kus_timed = ev0.elapsed_time(ev1) * 1e3 / K
         kfrag = par.FragmentBuffers(1024, n, D, device) if T != 1024 else frags[0]
         if kfrag is not frags[0]:
@@ -541,16 +543,17 @@ def main():
                                                          "separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 calibration"),
                            "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps}
         if persistent:
-            own = PERSISTENT_OWN_BYTES * n * steps_per_launch / (kus * 1e-6) / 1e9
+            own_b = persistent_own_bytes(D)
+            own = own_b * n * steps_per_launch / (kus * 1e-6) / 1e9
             out["roofline"].update({
-                "kernel_own_bytes_per_env_step": PERSISTENT_OWN_BYTES,
+                "kernel_own_bytes_per_env_step": own_b,
                 "achieved_kernel_own_bytes": own, "frac_kernel_own_bytes": own / HBM_PEAK_GBS,
-                "note": "achieved / frac price the launch at SURVEY 8d's 309 B per env-step (the definition the metric is graded on: state R/W, "
-                        "action, parameters, counter, row, reward, flag).  The persistent kernel does not move the 200 B of state, parameter "
+                "note": "achieved / frac price the launch at SURVEY 8d's %d B per env-step (the definition the metric is graded on: state R/W, "
+                        "action, parameters, counter, row, reward, flag).  The persistent kernel does not move the state, parameter "
                         "and counter traffic at all -- they stay in registers / LDS between steps -- so what actually crosses the memory "
-                        "system is 109 B per env-step (achieved_kernel_own_bytes / frac_kernel_own_bytes; `traffic` is the PMC count).  "
+                        "system is %d B per env-step (achieved_kernel_own_bytes / frac_kernel_own_bytes; `traffic` is the PMC count).  "
                         "At 4096 envs the launch occupies 64 of 256 CUs and is a dependent instruction chain per step (DESIGN.md section 4), "
-                        "not bandwidth: the env-count sweep in `extras` shows where the same kernels meet the roofline."})
+                        "not bandwidth: the env-count sweep in `extras` shows where the same kernels meet the roofline." % (ALG_BYTES[alg], own_b)})
         else:
             out["roofline"]["note"] = ("per-step launches: at small batches the launch is a dependent instruction chain between two kernel "
                                        "boundaries, not HBM-bound (DESIGN.md; env-count sweep in `extras`)")
@@ -643,7 +646,7 @@ def main():
                     e4, alg4 = make_env(other, n4, 5, device)
                     (e4.reset() if other == "config2" else e4.vector_reset_tensor())
                     lo4, hi4 = (0.5, 1.0) if other == "config2" else (0.0, 1.0)
-                    # qd_step_fragment on 1024-step fragments (these configurations: one kernel launch per step, replayed from a HIP graph)
+                    # qd_step_fragment on 1024-step fragments (one persistent launch per fragment; extras.<config>_kernel names the kernel)
                     f4 = par.FragmentBuffers(1024, n4, e4._dev.D, device)
                     f4.actions.copy_(lo4 + (hi4 - lo4) * torch.rand(f4.actions.shape, device=device, dtype=torch.float32))
                     p4, _ = kernel_period_us(e4, f4)

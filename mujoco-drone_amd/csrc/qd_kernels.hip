@@ -1373,6 +1373,13 @@ static bool qd_fragment_is_persistent(const qd_env* env) {
   if (env->spec == SPEC_LSTM || env->spec == SPEC_GENERIC_FS1) return env->ka.n <= qd_persistent_max_envs() && env->ka.n <= qd_persistent_max_envs_other();
   return false;
 }
+// The single-body model (SimpleDrone, and BaseDroneEnv without the load): its step is ~500 float32 instructions, too short to be
+// worth a split over waves, so a fragment runs in k_rollout -- one wavefront per 64 envs, state in registers, rows through the
+// wave's LDS tile.  Measured against the per-step launches (tests/diag_rollout_simple.py, BASELINE config 2): 1.57 / 3.51 us per
+// step at 4096 envs, 2.03 / 5.13 at 65536, 24.8 / 54.7 at 2^20 (4.2e10 env-steps/s).
+static bool qd_fragment_is_rollout(const qd_env* env) {
+  return qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && !env->load && env->spec != SPEC_FLOOR;
+}
 
 int qd_set_option(qd_env* env, int option, int value) {
   QD_NEED(env);
@@ -1395,6 +1402,11 @@ const char* qd_step_kernel_name(const qd_env* env) {
 }
 const char* qd_fragment_kernel_name(const qd_env* env) {
   if (!env) return "";
+  if (qd_fragment_is_rollout(env)) {
+    static thread_local char buf[64];
+    snprintf(buf, sizeof buf, "qd::k_rollout<false,64,%d>", env->spec);
+    return buf;
+  }
   if (!qd_fragment_is_persistent(env)) return qd_step_kernel_name(env);
   const bool two = env->ka.n > 256 * 64;
   return env->spec == SPEC_RMA ? "qd::k_rollout_coop<1,2>"
@@ -1413,6 +1425,7 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
     QD_HIP(launch_rollout_coop(env->ka, env->spec, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
+  if (qd_fragment_is_rollout(env)) return qd_rollout(env, actions, T, obs, reward, truncated, stream);
   qd_env::Frag* fr = nullptr;
   for (auto& f : env->frag)
     if (f.T == T && f.actions == actions && f.obs == obs && f.reward == reward && f.trunc == truncated) fr = &f;

@@ -419,3 +419,73 @@ def test_config5_full_size_fragment_vs_oracle_200_steps(qd, orc):
     assert div.max("mixed") < 1e-4 and div.max("rel") < 1e-4
     assert worst_acc < 2e-3
     np.testing.assert_allclose(gs, ob.sensor, rtol=2e-4, atol=2e-3)
+
+
+# ------------------------------------------------------------------ the single-body model: fragments run in k_rollout
+def test_config2_full_size_fragment_vs_oracle_and_per_step(qd, orc):
+    """BASELINE config 2 at its full size through qd_step_fragment (k_rollout<false,64,SPEC_SIMPLE>: one wavefront per 64 envs keeps
+    the state in registers for the whole fragment): 4096 SimpleDrone envs, fixed initial state, 200 steps of U[0.5, 1) rotor
+    actions as four 50-step fragments; every env against the float64 oracle (<= 1e-4 relative), every step's rows, rewards and
+    flags against the oracle's and against the per-step kernel's"""
+    rng = np.random.default_rng(321)
+    n, L, steps, F = 4096, qd._lib, 200, 50
+    c = make_cfg(L, n, load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, h=0.001, ctrl_map=0, term=1,
+                 ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0), max_steps=10 ** 6, max_distance=1e9)
+    env, per = qd.dev.DeviceEnv(c), qd.dev.DeviceEnv(c)
+    assert env.fragment_kernel_name() == "qd::k_rollout<false,64,3>", env.fragment_kernel_name()
+    raw = np.tile([1.35, 0.15, 7.5, 0.015, 0, 0], (n, 1))
+    q0 = np.tile([0, 0, 1, 1, 0, 0, 0.0], (n, 1))
+    for e in (env, per):
+        e.set_params(raw)
+        e.set_state(q0, np.zeros((n, 6)), np.zeros((n, 4)))
+    ob = orc.Batch(raw, False, L.OBS_KINDS.index("SimpleDrone"), L.REWARD_KINDS.index("simple_drone_reward"), 0.001, 2, 0, (0, 0, 1, 0), 1e9, 10 ** 6)
+    ob.qpos[:], ob.qvel[:], ob.act[:] = q0, 0.0, 0.0
+    acts = rng.uniform(0.5, 1.0, (steps, n, 4)).astype(np.float32)
+    dacts = torch.as_tensor(acts).cuda()
+    O, R, Tr = _bufs(F, n, 6)
+    wo = wr = wp = 0.0
+    for f in range(steps // F):
+        env.step_fragment(dacts[f * F:(f + 1) * F].contiguous(), O, R, Tr)
+        Oh, Rh, Th = O.cpu().numpy().astype(np.float64), R.cpu().numpy().astype(np.float64), Tr.cpu().numpy()
+        for t in range(F):
+            oo, orr, otr = ob.step(acts[f * F + t].astype(np.float64), threads=8)
+            o, r, tr = per.step(dacts[f * F + t])
+            d = np.abs(Oh[t] - oo)
+            d[:, 3:] = np.minimum(d[:, 3:], np.abs(d[:, 3:] - 2 * np.pi))      # the three angles wrap at +-pi
+            dp = (O[t] - o).abs()
+            dp[:, 3:] = torch.minimum(dp[:, 3:], (dp[:, 3:] - 2 * np.pi).abs())
+            wo, wr = max(wo, float(d.max())), max(wr, float(np.abs(Rh[t] - orr).max()))
+            wp = max(wp, float(dp.max()), float((R[t] - r).abs().max()))
+            assert np.array_equal(Th[t].astype(bool), otr.astype(bool)) and torch.equal(Tr[t], tr)
+    gq, gv, ga, _, gk = [x.cpu().numpy().astype(np.float64) for x in env.get_state()]
+    assert np.all(gk == steps)
+    err = max(float(np.max(np.abs(g - w) / np.maximum(1.0, np.abs(w)))) for g, w in ((gq, ob.qpos), (gv, ob.qvel), (ga, ob.act)))
+    print("config 2 through k_rollout, 4096 envs, 200 steps: max relative state divergence %.3e; rows |obs - oracle| %.3e, "
+          "|reward - oracle| %.3e; against the per-step kernel %.3e" % (err, wo, wr, wp))
+    assert err < 1e-4 and wo < 2e-4 and wr < 2e-4 and wp < 2e-5
+
+
+def test_simple_drone_fragments_with_resets(qd):
+    """SimpleDrone.reset_model sampling inside a fragment (QD_START_SIMPLE: qpos0 + U(-0.03, 0.03), only drone 0 moved to start_pos)
+    and the BaseDroneEnv observation variants on the single-body model: fragments equal per-step launches"""
+    L, n, T = qd._lib, 300, 40
+    cases = [dict(load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, h=0.001, ctrl_map=0, term=1,
+                  ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0), start=2, auto_reset=1, max_steps=9, max_distance=4.0),
+             dict(load=False, obs="LocalFrameRPYEnv", reward="distance_energy_reward", start=1, random_params=1, auto_reset=1, max_steps=9)]
+    for kw in cases:
+        mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, seed=4, **kw))
+        a, b = mk(), mk()
+        a.reset(); b.reset()
+        assert "k_rollout<false" in a.fragment_kernel_name()
+        lo = 0.5 if kw["obs"] == "SimpleDrone" else 0.0
+        for rep in range(2):
+            acts = lo + (1 - lo) * torch.rand((T, n, 4), device="cuda")
+            O, R, Tr = _bufs(T, n, a.D)
+            a.step_fragment(acts, O, R, Tr)
+            for t in range(T):
+                o, r, tr = b.step(acts[t])
+                assert torch.equal(Tr[t], tr), (kw["obs"], rep, t)
+                d = (O[t] - o).abs()
+                d[:, 3:6] = torch.minimum(d[:, 3:6], (d[:, 3:6] - 2 * np.pi).abs())
+                assert float(d.max()) <= 2e-5 and float((R[t] - r).abs().max()) <= 2e-5, (kw["obs"], rep, t, float(d.max()))
+        assert int(Tr.sum()) > 0

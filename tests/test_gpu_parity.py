@@ -940,6 +940,8 @@ def test_step_fragment_graph_replay_equals_steps(qd):
     cfg = dict(base_config, num_drones=n, reward_fcn=distance_reward_fcn, random_params=True, param_difficulty=1,
                state_difficulty=0.2, max_steps=10, regen_env_at_steps=3 * T, auto_reset=True)
     e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    e1._dev.set_option(qd._lib.OPT_PERSISTENT_FRAGMENTS, 0)                # this test is about the graph path
+    assert "k_step" in e1._dev.fragment_kernel_name()
     e1.vector_reset_tensor(); e2.vector_reset_tensor()
     kw = dict(device="cuda")
     acts = torch.rand((T, n, 4), **kw)
@@ -1005,6 +1007,8 @@ def test_step_fragment_policies_long_and_short_runs(qd):
     cfg = dict(base_config, num_drones=n, reward_fcn=distance_reward_fcn, random_params=True, param_difficulty=1,
                state_difficulty=0.2, max_steps=40, auto_reset=True)
     e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    e1._dev.set_option(qd._lib.OPT_PERSISTENT_FRAGMENTS, 0)                # the per-step launches, not the persistent kernel
+    assert "k_step" in e1._dev.fragment_kernel_name()
     e1.vector_reset_tensor(); e2.vector_reset_tensor()
     for T in (130, 20):
         acts = torch.rand((T, n, 4), device="cuda")
