@@ -1361,10 +1361,11 @@ static int qd_persistent_max_envs() {
   static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS"); return e ? atoi(e) : 0x7fffffff; }();
   return v;
 }
-// (the sensor-carrying / run-time-dispatched instantiations spill under the two-workgroups-per-CU register cap and lose to the
-// 256-thread per-step kernel at very large batches: config 5 at 2^20 envs 118 against 105 us per step; QD_PERSISTENT_MAX_ENVS_OTHER)
+// (the sensor-carrying / run-time-dispatched instantiations: measured with config 5 against its per-step kernels, steady state,
+// 1.87 / 5.43 us per step at 8192 envs, 3.39 / 9.72 at 32768, 23.8 / 31.0 at 262144, 92.6 / 100.1 at 2^20; QD_PERSISTENT_MAX_ENVS_OTHER
+// limits them separately for experiments)
 static int qd_persistent_max_envs_other() {
-  static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS_OTHER"); return e ? atoi(e) : 262144; }();
+  static const int v = [] { const char* e = getenv("QD_PERSISTENT_MAX_ENVS_OTHER"); return e ? atoi(e) : 0x7fffffff; }();
   return v;
 }
 static bool qd_fragment_is_persistent(const qd_env* env) {

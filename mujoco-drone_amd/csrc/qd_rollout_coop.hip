@@ -34,6 +34,8 @@
 // computes it and whenever, the result is the same: wave A only ever READS the pool, takes the entry tagged with its counter
 // if it is there and samples inline if not (slower, same result) -- the hand-over is the workgroup barrier, there is no
 // two-slot global protocol and no fence.  Counted like in the per-step kernels (qd_pool_counters).
+#include <cstdlib>
+
 #include "qd_env_device.h"
 
 namespace qd {
@@ -152,7 +154,13 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
   const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
   const int rounds = T + (sens ? 1 : 0);
   __shared__ RcLds L;
+#ifdef RC_ROTATE
+  // experiment: the two workgroups of a CU with complementary wave -> role maps, so that no SIMD hosts two solver waves
+  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int role = (((int)blockIdx.x >> RC_ROTATE) & 1) ? (wv ^ 1) : wv;
+#else
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+#endif
   const int lane = threadIdx.x & 63;
   const int base_env = blockIdx.x * 64;
   const int i = base_env + lane;
@@ -493,10 +501,17 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
 hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
   KArgs kk = k;
   kk.main_blocks = (k.n + 63) / 64;
-  // the workgroup's own sampler costs no extra workgroups, so the pool is on at every batch size (qd_create switches the ARENA
-  // pool off from 32768 envs, where sampler workgroups no longer find idle SIMDs); entries are a pure function of
-  // (seed, env, episode), so the per-step kernels can use or ignore what this kernel leaves in the arena
-  kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED) ? 1 : 0;
+  // The workgroup's own sampler (wave C's phase 2) pays while a workgroup has its CU to itself (<= 256 workgroups = 16384 envs):
+  // there a truncating lane that samples inline stalls its whole workgroup for ~5500 cycles.  With two workgroups per CU the other
+  // workgroup fills that hole, and a sampler chunk in EVERY step costs more issue slots than it saves: measured in the steady
+  // state of config 3 (0.45 truncations per step per 64 envs, tests/diag_persistent_big.py with QD_DIAG_WARM_STEPS=1536) 2.95 us
+  // per step with the sampler against 2.62 without at 32768 envs, 91.7 against 72.8 at 2^20.  Entries are a pure function of
+  // (seed, env, episode): results are the same either way, and the per-step kernels can use or ignore what is left in the arena.
+  // QD_RC_POOL_MAX_ENVS moves the limit (experiments).
+  {
+    static const int pool_max = [] { const char* e = getenv("QD_RC_POOL_MAX_ENVS"); return e ? atoi(e) : 256 * 64; }();
+    kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED && k.n <= pool_max) ? 1 : 0;
+  }
   const dim3 grid(kk.main_blocks), block(RC_THREADS);
   (void)hipGetLastError();
   const bool two = kk.main_blocks > 256;   // more workgroups than CUs: the second slot per CU is worth its register cap

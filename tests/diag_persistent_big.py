@@ -14,13 +14,17 @@ envs = [int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "4096,16384,32768
 for n in envs:
     T = 256 if n <= 65536 else (64 if n <= 1048576 else 16)
     for persistent in (1, 0):
-        env, _ = bench.make_env("config3", n, 7, "cuda:0")
+        env, _alg = bench.make_env(os.environ.get("QD_DIAG_CONFIG", "config3"), n, 7, "cuda:0")
         env.vector_reset_tensor()
         env._dev.set_option(L.OPT_PERSISTENT_FRAGMENTS, persistent)
         f = par.FragmentBuffers(T, n, env._dev.D, "cuda:0")
         f.actions.copy_(torch.rand(f.actions.shape, device="cuda"))
+        for _ in range(int(os.environ.get("QD_DIAG_WARM_STEPS", "0")) // T):      # into the steady state of truncations and resets
+            env._dev.step_fragment(f.actions, f.obs, f.rewards, f.truncated)
         p, k = bench.kernel_period_us(env, f, launches=max(4 * T, 1024 if n <= 65536 else 0))
-        print("n=%8d T=%4d %-28s %9.3f us per step = %.3e env-steps/s = %5.1f %% of 8 TB/s at 309 B" % (
-            n, T, env._dev.fragment_kernel_name(), p, n / p * 1e6, 309 * n / (p * 1e-6) / 8e12 * 100), flush=True)
+        if os.environ.get("QD_DIAG_WARM_STEPS"):
+            print("   truncations per step per 64 envs in the last fragment: %.3f" % (float(f.truncated.sum()) / T / (n / 64)))
+        print("n=%8d T=%4d %-28s %9.3f us per step = %.3e env-steps/s = %5.1f %% of 8 TB/s at SURVEY 8d's bytes" % (
+            n, T, env._dev.fragment_kernel_name(), p, n / p * 1e6, bench.ALG_BYTES[_alg] * n / (p * 1e-6) / 8e12 * 100), flush=True)
         del env, f
         torch.cuda.empty_cache()

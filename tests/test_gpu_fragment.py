@@ -111,7 +111,9 @@ def test_fragment_is_batch_and_cut_invariant(qd, N):
         assert torch.equal(x[:64], y)
     names = qd.dev.ARENA_PLANES
     pb, ps = big.planes()[:, :64], small.planes()
-    for k, name in enumerate(names):                              # everything the arena holds, the reset pool included
+    for k, name in enumerate(names):                              # everything the arena holds; the reset pool too while both batches
+        if N > 16384 and name.startswith(("NX", "NY")):           # run the in-workgroup sampler (above 16384 envs lanes sample inline:
+            continue                                              # same states, nothing left in the pool planes)
         assert torch.equal(pb[k], ps[k]), "arena plane %s" % name
 
 
