@@ -59,6 +59,11 @@ def make_cfg(L, n, load=True, obs="LocalFrameRPYParamsEnv", reward="distance_ene
     return c
 
 
+# Derived outputs (observation rows, rewards) against the float64 oracle's, absolute: 2 x the maxima measured on MI355X (printed
+# by the tests that use them; round 2 used 2e-3 ... 3e-3 throughout)
+OBS_TOL_CFG3, REW_TOL_CFG3 = 4e-4, 1.5e-3  # config 3, all 4096 envs at step 200: measured 1.9e-4 / 7.0e-4 (positions of 15 m, d^2 of 16 in the reward)
+OBS_TOL_CFG5, REW_TOL_CFG5 = 2e-5, 2e-5    # config 5 / moving waypoints over 25-30 steps: measured 7.1e-6 / 6.3e-6
+
 CENTER = np.array([1, 0.17, 7, 0.01, 1.2, 0.3])
 WIDTH = np.array([0.1, 0.02, 1, 0.0025, 0.2, 0.05])
 
@@ -562,6 +567,7 @@ def test_moving_waypoint_circle_config5(qd, orc):
     models = [orc.build_model(raw[i]) for i in range(n)]
     oq, ov, oa = qpos.astype(np.float32).astype(np.float64), qvel.astype(np.float32).astype(np.float64), act.astype(np.float32).astype(np.float64)
     ok, rk = L.OBS_KINDS.index(obs), L.REWARD_KINDS.index(rew)
+    worst = [0.0, 0.0]
     for k in range(steps):
         a = rng.uniform(0, 1, (n, 4)).astype(np.float32)
         o, r, tr = env.step(a)
@@ -572,8 +578,12 @@ def test_moving_waypoint_circle_config5(qd, orc):
             q, v, aa, sens = orc.step(models[i], 0.01, 1, oq[i], ov[i], oa[i], 0.1 + 0.9 * a[i].astype(np.float64))
             oq[i], ov[i], oa[i] = q, v, aa
             s = orc.drone_state(1, q, v, sens, aa, ref, raw[i])
-            np.testing.assert_allclose(o[i], orc.obs(ok, s, ref), rtol=2e-4, atol=3e-3)
-            assert abs(r[i] - orc.reward(rk, s, a[i], k + 1, ref, 1e9)) < 2e-3 * max(1.0, abs(r[i]))
+            wo, wr = orc.obs(ok, s, ref), orc.reward(rk, s, a[i], k + 1, ref, 1e9)
+            d = np.abs(o[i] - wo)
+            d[5] = min(d[5], abs(d[5] - 2 * np.pi))                      # the heading error wraps at +-pi
+            worst[0], worst[1] = max(worst[0], float(d.max())), max(worst[1], abs(float(r[i]) - wr))
+            assert d.max() < OBS_TOL_CFG5 and abs(r[i] - wr) < REW_TOL_CFG5, (i, k, float(d.max()), abs(float(r[i]) - wr))
+    print("moving waypoint, %d steps: max |obs - oracle| %.3e, max |reward - oracle| %.3e" % (steps, worst[0], worst[1]))
     st = env.drone_states().cpu().numpy()            # reference entries of the state vector follow the waypoint too
     ph = 2 * np.pi * 0.5 * steps * 0.01 + 2 * np.pi * np.arange(n) / n
     np.testing.assert_allclose(st[:, 23], 0.5 + np.cos(ph), atol=1e-5)
@@ -646,8 +656,11 @@ def test_config3_full_size_4096_envs_200_steps(qd, orc):
     print(div.table("config 3 at step 200, all 4096 envs (abs in m, rad, m/s, rad/s; rel = abs / the group's scale)"))
     assert err < 1e-4
     assert div.max("rel") < 1e-4
-    np.testing.assert_allclose(o.cpu().numpy(), oo, rtol=2e-4, atol=2e-3)
-    np.testing.assert_allclose(r.cpu().numpy(), orr, rtol=2e-4, atol=2e-3)
+    do = np.abs(o.cpu().numpy() - oo)
+    do[:, 5] = np.minimum(do[:, 5], np.abs(do[:, 5] - 2 * np.pi))
+    dr = np.abs(r.cpu().numpy() - orr)
+    print("config 3 at step 200: max |obs - oracle| %.3e, max |reward - oracle| %.3e" % (do.max(), dr.max()))
+    assert do.max() < OBS_TOL_CFG3 and dr.max() < REW_TOL_CFG3
 
 
 def test_config2_full_size_4096_simple_drones_200_steps(qd, orc):
@@ -1095,6 +1108,7 @@ def test_config5_full_size_8192_envs(qd, orc):
     ok, rk = L.OBS_KINDS.index("LocalFrameFullStateEnv"), L.REWARD_KINDS.index("distance_energy_reward_pendulum_en4")
     centre = np.array([float(x) for x in env.reference])
     g = torch.Generator(device="cuda").manual_seed(3)
+    worst = [0.0, 0.0]
     for k in range(steps):
         a = torch.rand((n, 4), generator=g, device="cuda")
         o, r, tr = env.vector_step_tensor(a)
@@ -1106,8 +1120,12 @@ def test_config5_full_size_8192_envs(qd, orc):
             q, v, aa, sens = orc.step(models[i], 0.01, 1, oq[i], ov[i], oa[i], 0.1 + 0.9 * an[i].astype(np.float64))
             oq[i], ov[i], oa[i] = q, v, aa
             s = orc.drone_state(1, q, v, sens, aa, ref, raw[i])
-            np.testing.assert_allclose(o[i], orc.obs(ok, s, ref), rtol=2e-4, atol=3e-3, err_msg="env %d step %d" % (i, k))
-            assert abs(r[i] - orc.reward(rk, s, an[i], k + 1, ref, 4.0)) < 2e-3 * max(1.0, abs(r[i])), (i, k)
+            wo, wr = orc.obs(ok, s, ref), orc.reward(rk, s, an[i], k + 1, ref, 4.0)
+            d = np.abs(o[i] - wo)
+            d[5] = min(d[5], abs(d[5] - 2 * np.pi))
+            worst[0], worst[1] = max(worst[0], float(d.max())), max(worst[1], abs(float(r[i]) - wr))
+            assert d.max() < OBS_TOL_CFG5 and abs(r[i] - wr) < REW_TOL_CFG5, (i, k, float(d.max()), abs(float(r[i]) - wr))
+    print("config 5, 8192 envs, %d steps (sample of envs): max |obs - oracle| %.3e, max |reward - oracle| %.3e" % (steps, worst[0], worst[1]))
     st = env._dev.drone_states().cpu().numpy()
     ph = 2 * np.pi * 0.5 * steps * 0.01 + 2 * np.pi * np.arange(n) / n
     np.testing.assert_allclose(st[:, 23], centre[0] + np.cos(ph), atol=2e-5)
