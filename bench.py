@@ -511,7 +511,8 @@ def main():
         kname = env._dev.fragment_kernel_name()
         persistent = "k_rollout" in kname
         kus_timed = ev0.elapsed_time(ev1) * 1e3 / K
-        kfrag = par.FragmentBuffers(1024, n, D, device) if T != 1024 else frags[0]
+        kT = 1024 if n <= 65536 else T       # (a 1024-step fragment of 2^20 envs would be 117 GB)
+        kfrag = par.FragmentBuffers(kT, n, D, device) if T != kT else frags[0]
         if kfrag is not frags[0]:
             kfrag.actions.copy_(lo + (hi - lo) * torch.rand(kfrag.actions.shape, generator=g, device=device, dtype=torch.float32))
         us_per_step, ksteps_measured = kernel_period_us(env, kfrag)
@@ -530,9 +531,9 @@ def main():
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                            "kernel_us": kus, "env_steps_per_launch": n * steps_per_launch, "steps_per_launch": steps_per_launch,
                            "us_per_step": us_per_step,
-                           "kernel_us_source": "HIP events on the launch stream around %d back-to-back launches of %s (1024-step "
+                           "kernel_us_source": "HIP events on the launch stream around %d back-to-back launches of %s (%d-step "
                                                "fragments, %d env steps per env), independent of --steps"
-                                               % (ksteps_measured // steps_per_launch, kname, ksteps_measured),
+                                               % (ksteps_measured // steps_per_launch, kname, kfrag.T, ksteps_measured),
                            "algorithmic_bytes_per_env_step": ALG_BYTES[alg],
                            "timed_region_us_per_step": kus_timed, "isolated_per_step_launch_us": iso_us,
                            "rocprofv3_avg_kernel_us": prof_us,

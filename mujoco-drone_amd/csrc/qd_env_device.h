@@ -14,6 +14,7 @@
 #include "qd_math.h"
 #include "qd_model.h"
 #include "qd_obsrew.h"
+#include "qd_pid.h"
 #include "qd_rng.h"
 
 namespace qd {
@@ -586,8 +587,34 @@ __device__ __forceinline__ void coop_obs_part(const KArgs& a, int i, int lane, c
     if ((((MASK >> k) & 1u) != 0u) == FRAME) row[k] = o[k];
 }
 
+// ---- analytic PID cascade (models/Analytic/*.py driven as attitude_test.py:36-47) ----
+__device__ __forceinline__ void load_pid(const KArgs& a, int i, PidState<float>& c) {
+  const float4 c0 = a.g[G_C0 * a.npad + i], c1 = a.g[G_C1 * a.npad + i], c2 = a.g[G_C2 * a.npad + i], c3 = a.g[G_C3 * a.npad + i];
+  c.pos_i[0] = c0.x; c.pos_i[1] = c0.y; c.pos_i[2] = c0.z; c.first = __float_as_uint(c0.w);
+  c.pos_prev[0] = c1.x; c.pos_prev[1] = c1.y; c.pos_prev[2] = c1.z;
+  c.att_i[0] = c2.x; c.att_i[1] = c2.y; c.att_i[2] = c2.z;
+  c.att_prev[0] = c3.x; c.att_prev[1] = c3.y; c.att_prev[2] = c3.z;
+}
+__device__ __forceinline__ void store_pid(const KArgs& a, int i, const PidState<float>& c) {
+  a.g[G_C0 * a.npad + i] = make_float4(c.pos_i[0], c.pos_i[1], c.pos_i[2], __uint_as_float(c.first));
+  a.g[G_C1 * a.npad + i] = make_float4(c.pos_prev[0], c.pos_prev[1], c.pos_prev[2], 0.f);
+  a.g[G_C2 * a.npad + i] = make_float4(c.att_i[0], c.att_i[1], c.att_i[2], 0.f);
+  a.g[G_C3 * a.npad + i] = make_float4(c.att_prev[0], c.att_prev[1], c.att_prev[2], 0.f);
+}
+// the controller's inputs are entries 0:6 of the drone state vector (get_drone_states: xyz, rpy of the normalised quaternion)
+__device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRegs& e) {
+  const float qn = frsq(e.s.qw * e.s.qw + e.s.qx * e.s.qx + e.s.qy * e.s.qy + e.s.qz * e.s.qz);
+  const float xyz[3] = {e.s.px, e.s.py, e.s.pz};
+  float rpy[3], act[4];
+  quat2rpy(e.s.qw * qn, e.s.qx * qn, e.s.qy * qn, e.s.qz * qn, &rpy[0], &rpy[1], &rpy[2]);
+  pid_action(c, e.ref, xyz, rpy, pid_mass(e.par), pid_motor_force(e.par), act);
+  return make_float4(act[0], act[1], act[2], act[3]);
+}
+
 // qd_rollout_coop.hip: T steps of the load model (SPEC_RMA, SPEC_LSTM or SPEC_GENERIC_FS1: one substep per step) in ONE launch,
 // four wavefronts per 64 envs.  `k` as qd_step would pass it (main_blocks is set by the launcher).
-hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
+// `pid`: the analytic PID cascade (qd_pid.h) is the action source (actions = nullptr, actions_out [T,N,4] nullable), else `actions` [T,N,4].
+hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream,
+                               bool pid = false, float* actions_out = nullptr);
 
 }  // namespace qd

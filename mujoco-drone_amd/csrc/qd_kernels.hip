@@ -472,30 +472,6 @@ __global__ __launch_bounds__(BLOCK) void k_rollout(KArgs a, int T, const float* 
   if (live) store_env(a, i, e);
 }
 
-// ---- analytic PID cascade (models/Analytic/*.py driven as attitude_test.py:36-47) ----
-__device__ __forceinline__ void load_pid(const KArgs& a, int i, PidState<float>& c) {
-  const float4 c0 = a.g[G_C0 * a.npad + i], c1 = a.g[G_C1 * a.npad + i], c2 = a.g[G_C2 * a.npad + i], c3 = a.g[G_C3 * a.npad + i];
-  c.pos_i[0] = c0.x; c.pos_i[1] = c0.y; c.pos_i[2] = c0.z; c.first = __float_as_uint(c0.w);
-  c.pos_prev[0] = c1.x; c.pos_prev[1] = c1.y; c.pos_prev[2] = c1.z;
-  c.att_i[0] = c2.x; c.att_i[1] = c2.y; c.att_i[2] = c2.z;
-  c.att_prev[0] = c3.x; c.att_prev[1] = c3.y; c.att_prev[2] = c3.z;
-}
-__device__ __forceinline__ void store_pid(const KArgs& a, int i, const PidState<float>& c) {
-  a.g[G_C0 * a.npad + i] = make_float4(c.pos_i[0], c.pos_i[1], c.pos_i[2], __uint_as_float(c.first));
-  a.g[G_C1 * a.npad + i] = make_float4(c.pos_prev[0], c.pos_prev[1], c.pos_prev[2], 0.f);
-  a.g[G_C2 * a.npad + i] = make_float4(c.att_i[0], c.att_i[1], c.att_i[2], 0.f);
-  a.g[G_C3 * a.npad + i] = make_float4(c.att_prev[0], c.att_prev[1], c.att_prev[2], 0.f);
-}
-// the controller's inputs are entries 0:6 of the drone state vector (get_drone_states: xyz, rpy of the normalised quaternion)
-__device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRegs& e) {
-  const float qn = frsq(e.s.qw * e.s.qw + e.s.qx * e.s.qx + e.s.qy * e.s.qy + e.s.qz * e.s.qz);
-  const float xyz[3] = {e.s.px, e.s.py, e.s.pz};
-  float rpy[3], act[4];
-  quat2rpy(e.s.qw * qn, e.s.qx * qn, e.s.qy * qn, e.s.qz * qn, &rpy[0], &rpy[1], &rpy[2]);
-  pid_action(c, e.ref, xyz, rpy, pid_mass(e.par), pid_motor_force(e.par), act);
-  return make_float4(act[0], act[1], act[2], act[3]);
-}
-
 __global__ __launch_bounds__(64) void k_pid_reset(KArgs a, const uint8_t* __restrict__ mask) {
   const int i = blockIdx.x * 64 + threadIdx.x;
   if (i >= a.n || (mask && !mask[i])) return;
@@ -1571,6 +1547,10 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
       if (rc == QD_OK && k.auto_reset) rc = qd_pid_reset(env, truncated + (size_t)t * k.n, stream);
       if (rc != QD_OK) return rc;
     }
+    return QD_OK;
+  }
+  if (qd_fragment_is_persistent(env)) {   // the controller rides in the epilogue wave of the persistent fragment kernel
+    QD_HIP(launch_rollout_coop(k, env->spec, T, nullptr, obs, reward, truncated, S(stream), true, actions_out));
     return QD_OK;
   }
   const dim3 grid(blocks64(k.n)), block(64);

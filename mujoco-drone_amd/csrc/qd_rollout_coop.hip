@@ -50,6 +50,7 @@ struct RcLds {
   float4 pre[6][64];      // A -> D: the state after the step and BEFORE the reset, truncated lanes only (the reward is of this state)
   uint4 info[64];         // A -> C, D: (bit 0 truncated | bit 1 reset), episode counter of s_{t+1}, num_steps after the step, -
   float4 nxt[2][5][64];   // the reset pool: slot e & 1 = entry of episode e, planes as in the arena (tag plane last)
+  float4 act[64];         // C -> A, D: the controller's action for this step (PID instantiations)
   float4 acc[64];         // A -> D: the accelerometer reading of the previous round (sensor-reading observation variants)
   float4 acc2[64];        // A -> D: the reading at the state the fragment ends in (the extra half round)
   float tile[2][64 * QD_MAX_OBS];   // wave D: the group's observation rows, row-major like the global span; two, because the rows
@@ -146,9 +147,16 @@ __device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rh
 // and cost SPEC_RMA nothing (251 registers, no scratch); the sensor-carrying and run-time-dispatched instantiations spill a
 // dozen registers under that cap, so batches that leave the second slot empty anyway (<= 16384 envs = 256 workgroups) run
 // their OCC = 1 instantiation.
-template <int SPEC, int OCC>
+//
+// PID: the action source is the reference's analytic cascade (qd_pid.h; models/Analytic/*.py wired as attitude_test.py:36-47) instead
+// of an action tensor.  The action of step t is a function of s_t; wave C, which reads s_t at the start of every round and has the
+// shortest phase 1, evaluates the controller there (its memory stays in that wave's registers) and publishes the action before
+// barrier 1; wave A applies the activation filter at the start of phase 2, wave D reads it for the reward.  `actions_out` [T,N,4]
+// (nullable) receives the actions.
+template <int SPEC, int OCC, bool PID>
 __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
-                                                             float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
+                                                             float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
+                                                             float* __restrict__ actions_out) {
   static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM || SPEC == SPEC_GENERIC_FS1, "persistent fragment kernel: the load model, one substep per step");
   const int D = spec_runtime<SPEC>() ? a.D : spec_obs_dim<SPEC>();
   const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
@@ -180,7 +188,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
 
   if (role == 0) {
     // ================================================================ wave A: factorisation, solve, integration, resets
-    float4 act_next = actions4[il];
+    float4 act_next = PID ? make_float4(0.f, 0.f, 0.f, 0.f) : actions4[il];
     rc_put_state(L.st, lane, e.s);
     L.info[lane] = make_uint4(0u, e.episode, (uint32_t)e.num_steps, 0u);
     coop_barrier();   // P
@@ -189,23 +197,33 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
     M3<float> R;
     V3<float> w0 = mk<float>(0.f, 0.f, 0.f), acc_last = mk<float>(0.f, 0.f, 0.f);
     bool rst_last = false;
-    for (int t = 0; t < rounds; t++) {
+    for (int t = 0; t <= rounds; t++) {
       RC_STAMP(0);
       const bool half = t == T;   // `sens` only: the forward dynamics at s_T for the last row's sensor entries, nothing integrated
-      const float4 action = act_next;
-      if (t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       // ---------------------------------------------------------- phase 1
       if (sens && t >= 1) {   // the reading of round t - 1, from that round's factor and right-hand side (before they are replaced)
-        acc_last = rc_sensor(f, r, R, w0);
-        L.acc[lane] = make_float4(acc_last.x, acc_last.y, acc_last.z, 0.f);
+        // The ONLY place the reading is evaluated -- also for the one at s_T after the extra half round (t == rounds): two inlined
+        // copies of the same arithmetic fuse their multiply-adds differently, and a fragment cut would show in the last bit.
+        const V3<float> acc_t = rc_sensor(f, r, R, w0);
+        if (t == rounds) {
+          L.acc2[lane] = make_float4(acc_t.x, acc_t.y, acc_t.z, 0.f);
+          if (rst_last) acc_last = acc_t;
+        } else {
+          acc_last = acc_t;
+          L.acc[lane] = make_float4(acc_t.x, acc_t.y, acc_t.z, 0.f);
+        }
       }
+      if (t == rounds) break;
+      const float4 action = act_next;
+      if (!PID && t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
       f = mass_factor(e.M, tg, a.h);
-      if (!half) {
-        float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
+      auto filter = [&](float4 u) {   // ctrl map and the activation filter: the part of the Euler step that does not wait for the accelerations
+        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
         if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
         integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
-      }
+      };
+      if (!PID && !half) filter(action);
       rc_ref(a, i, e.num_steps, ref0, e.ref);
       // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
       // arithmetic across freely, and left alone it sinks two thirds of the factorisation into phase 2 -- onto the critical
@@ -235,6 +253,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
       if (!half) {
+        if (PID) filter(L.act[lane]);   // wave C evaluated the controller on s_t during phase 1
         Accel<float> im;
         V3<double> a0im;
         finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
@@ -279,16 +298,14 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
         rst_last = rst;
         rc_put_state(L.st, lane, e.s);
         L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
-      } else {
-        // the reading at s_T: the sensor entries of the last row where the last step reset the lane, and what mj_forward leaves
-        const V3<float> accT = rc_sensor(f, r, R, w0);
-        L.acc2[lane] = make_float4(accT.x, accT.y, accT.z, 0.f);
-        if (rst_last) acc_last = accT;
       }
+      // (the half round stops at the right-hand side: the reading at s_T -- the sensor entries of the last row where the last
+      // step reset the lane, and what mj_forward leaves in the arena -- is evaluated at the top of the loop like every other)
       RC_STAMP(3);
       coop_barrier();   // 2
       RC_STAMP(4);
     }
+    if (sens) coop_barrier();   // E: L.acc2 is published
     // the fragment's last step leaves what a per-step launch leaves: the state, and the accelerometer reading of that step
     // (quirk C-6: the reading of the state the step STARTED from; where a reset replaced or invalidated it, see above)
     if (live) {
@@ -316,6 +333,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       coop_barrier();   // 2
       RC_STAMP(4);
     }
+    if (sens) coop_barrier();   // E
   } else if (role == 2) {
     // ================================================================ wave C: gravity + velocity products; the reset sampler
     const bool pool = a.use_pool != 0 && a.auto_reset != 0;
@@ -342,6 +360,9 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
     jns.px = jns.py = jns.pz = jns.qw = jns.qx = jns.qy = jns.qz = jns.th1 = jns.th2 = 0.f;
     jns.vx = jns.vy = jns.vz = jns.wx = jns.wy = jns.wz = jns.thd1 = jns.thd2 = jns.a0 = jns.a1 = jns.a2 = jns.a3 = 0.f;
     int jphase = 0;
+    PidState<float> pc;   // PID instantiations: the controller pair of this lane's env (arena planes C0..C3 between launches)
+    pid_reset(pc);
+    if (PID) load_pid(a, il, pc);
     for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
       if (jphase == JOB_DONE) {   // commit: wave A is in its phase 1 and does not read the pool
@@ -350,8 +371,27 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       State<float> s;
       rc_get_state(L.st, lane, s);
-      const uint32_t episode = L.info[lane].y;
+      const uint4 info = L.info[lane];
+      const uint32_t episode = info.y;
       const float4 tag0 = L.nxt[0][4][lane], tag1 = L.nxt[1][4][lane];
+      if (PID && t < T) {
+        // The controller on s_t, for step t.  This wave's phase 1 is the shortest of the three, but the ~250 instructions of the
+        // cascade still make it the last one at barrier 1 (2.07 us per step against 1.48 with given actions; in wave D, which has
+        // the row to build, 2.18).  Tried and not kept: the controller in wave B's idle phase 2 with an in-phase hand-over to wave A
+        // (value, then a round tag wave A polls before it applies the filter) -- wave A then waits for the cascade inside its own
+        // phase 2 instead of at the barrier: 2.25 us.  A lane reset in the last step starts with fresh controller objects; the
+        // waypoint is that of the episode step s_t is at.
+        const bool rst = (info.x & 2u) != 0u;
+        if (rst) pid_reset(pc);
+        EnvRegs ed;
+        ed.s = s;
+        rc_ref(a, i, rst ? 0 : (int)info.z, ref0, ed.ref);
+#pragma unroll
+        for (int k = 0; k < 6; k++) ed.par[k] = e.par[k];
+        const float4 act_now = pid_env_action(pc, ed);
+        L.act[lane] = act_now;
+        if (actions_out && live) reinterpret_cast<float4*>(actions_out)[(size_t)t * n + i] = act_now;
+      }
       const Tether<float> tg = tether_geometry(s.th1, s.th2);
       V3<float> gt, w;
       gravity_body(s, &gt, &w);
@@ -389,6 +429,11 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       coop_barrier();   // 2
       RC_STAMP(4);
     }
+    if (sens) coop_barrier();   // E
+    if (PID && live) {   // the controller memory back to the arena (fresh objects where the last step reset the lane)
+      if ((L.info[lane].x & 2u) != 0u) pid_reset(pc);
+      store_pid(a, i, pc);
+    }
     // hand the pool back to the arena as the per-step kernels expect it: the entry of every env's current counter and of the
     // one after it, complete (what the chunked job had not finished is sampled here, once per fragment); entries are "state
     // only" (POOL_STATE): a per-step kernel of a sensor-reading configuration adds the second stage itself
@@ -415,7 +460,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
   } else {
     // ================================================================ wave D: observation rows, rewards, flags -- one round behind
     // (the sensor entries of a row and its write-out: two rounds behind, see the head of the kernel)
-    float4 act_prev = actions4[il];   // the action of step t - 1 when iteration t uses it
+    float4 act_prev = PID ? make_float4(0.f, 0.f, 0.f, 0.f) : actions4[il];   // the action of step t - 1 when iteration t uses it
     coop_barrier();   // P
     const int acc_at = sens ? rc_acc_slot(spec_obs<SPEC>(a)) : -1;
     const int rows = min(64, n - base_env);
@@ -431,10 +476,10 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       const bool row_now = t >= 1 && t <= T;   // the row of step t - 1 is the observation of s_t
       float* tile_now = L.tile[(t - 1) & 1];
       if (row_now) {
-        info = L.info[lane];
-        rst = (info.x & 2u) != 0u;
         EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
         rc_get_state(L.st, lane, ed.s);
+        info = L.info[lane];
+        rst = (info.x & 2u) != 0u;
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
         ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
         if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
@@ -443,6 +488,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       RC_STAMP(1);
       if (t < rounds) coop_barrier();   // 1
+      else if (sens) coop_barrier();    // E: the reading at s_T is published
       RC_STAMP(2);
       V3<float> acc_new = mk<float>(0.f, 0.f, 0.f);
       if (sens && t >= 1) {   // the reading of round t - 1 (wave A's phase 1 of this round); in the last iteration the one at s_T
@@ -490,7 +536,8 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       acc_prev = acc_new;
       rst_prev = rst;
-      if (t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
+      if (PID) { if (t < T) act_prev = L.act[lane]; }   // wave C's controller output of this round (published before barrier 1)
+      else if (t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
       RC_STAMP(3);
       if (t < rounds) coop_barrier();   // 2
       RC_STAMP(4);
@@ -498,7 +545,8 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
   }
 }
 
-hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
+hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream,
+                               bool pid, float* actions_out) {
   KArgs kk = k;
   kk.main_blocks = (k.n + 63) / 64;
   // The workgroup's own sampler (wave C's phase 2) pays while a workgroup has its CU to itself (<= 256 workgroups = 16384 envs):
@@ -515,11 +563,21 @@ hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* act
   const dim3 grid(kk.main_blocks), block(RC_THREADS);
   (void)hipGetLastError();
   const bool two = kk.main_blocks > 256;   // more workgroups than CUs: the second slot per CU is worth its register cap
-#define RC_LAUNCH(SPECV, OCCV) hipLaunchKernelGGL((k_rollout_coop<SPECV, OCCV>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc)
-  if (spec == SPEC_RMA) RC_LAUNCH(SPEC_RMA, 2);
-  else if (spec == SPEC_LSTM) { if (two) RC_LAUNCH(SPEC_LSTM, 2); else RC_LAUNCH(SPEC_LSTM, 1); }
-  else if (spec == SPEC_GENERIC_FS1) { if (two) RC_LAUNCH(SPEC_GENERIC_FS1, 2); else RC_LAUNCH(SPEC_GENERIC_FS1, 1); }
-  else return hipErrorInvalidValue;
+#define RC_LAUNCH(SPECV, OCCV, PIDV) \
+  hipLaunchKernelGGL((k_rollout_coop<SPECV, OCCV, PIDV>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc, actions_out)
+#define RC_BY_OCC(SPECV, PIDV) do { if (two) RC_LAUNCH(SPECV, 2, PIDV); else RC_LAUNCH(SPECV, 1, PIDV); } while (0)
+  if (!pid) {
+    if (spec == SPEC_RMA) RC_LAUNCH(SPEC_RMA, 2, false);
+    else if (spec == SPEC_LSTM) RC_BY_OCC(SPEC_LSTM, false);
+    else if (spec == SPEC_GENERIC_FS1) RC_BY_OCC(SPEC_GENERIC_FS1, false);
+    else return hipErrorInvalidValue;
+  } else {
+    if (spec == SPEC_RMA) RC_BY_OCC(SPEC_RMA, true);
+    else if (spec == SPEC_LSTM) RC_BY_OCC(SPEC_LSTM, true);
+    else if (spec == SPEC_GENERIC_FS1) RC_BY_OCC(SPEC_GENERIC_FS1, true);
+    else return hipErrorInvalidValue;
+  }
+#undef RC_BY_OCC
 #undef RC_LAUNCH
   return hipGetLastError();
 }

@@ -44,9 +44,12 @@ def select(rows, grid, cut):
     return rows
 
 
+LONGEST = 1024     # --longest: the step count of the longest launches of the profiled command (bench.py --fragment)
+
+
 def cut_mask(v, cut):
-    x = v / (v.max() / 1024.0)
-    return x >= 0.97 * 1024 if cut >= 1024 else (x >= 0.8 * cut) & (x <= 1.25 * cut + 8)
+    x = v / (v.max() / float(LONGEST))
+    return x >= 0.97 * LONGEST if cut >= LONGEST else (x >= 0.8 * cut) & (x <= 1.25 * cut + 8)
 
 
 def trace_stats(d, key="k_step", grid=0, cut=0):
@@ -92,6 +95,9 @@ def main():
             grid = int(sys.argv[j + 1])
         if a == "--cut":
             cut = int(sys.argv[j + 1])
+        if a == "--longest":
+            global LONGEST
+            LONGEST = int(sys.argv[j + 1])
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mujoco-drone_amd"))
     try:    # the library the profiled command loaded was built from these sources (bench.py checks the hash before quoting a profile)
         import build as _b

@@ -45,21 +45,28 @@ def short(name):     # "void qd::k_rollout_coop<1>(qd::KArgs, ...)" -> "qd::k_ro
 cur = {"_comment": "written by tools/install_profiles_r03.py from the rocprofv3 runs of tools/profile_r03.sh; bench.py quotes an entry only "
                    "when source_hash equals the loaded library's qd_source_hash()", "source_hash": None, "kernels": {}}
 hashes = set()
-for tag, conf, n in (("r03_default_n4096", "config3", 4096),):
+for tag, ptag, conf, n in (("r03_default_n4096", "r03_pmc_n4096", "config3", 4096),
+                           ("r03_pmc_config5_n8192", "r03_pmc_config5_n8192", "config5", 8192),
+                           ("r03_pmc_config2_n4096", "r03_pmc_config2_n4096", "config2", 4096),
+                           ("r03_pmc_config3_n1048576", "r03_pmc_config3_n1048576", "config3", 1048576),
+                           ("r03_pmc_config5_n1048576", "r03_pmc_config5_n1048576", "config5", 1048576),
+                           ("r03_pmc_config2_n1048576", "r03_pmc_config2_n1048576", "config2", 1048576)):
     if tag not in S:
         continue
     t = S[tag]["step_kernel_trace"]
     ent = {"rocprofv3_avg_kernel_us": t["avg_ns"] * 1e-3, "dispatches": t["dispatches"], "steps_per_launch": t.get("steps_per_launch", 1),
            "from": "profiles/%s_rocprof_summary.json" % tag}
     hashes.add(S[tag].get("source_hash"))
-    p = S.get(tag.replace("default", "pmc"))
+    p = S.get(ptag)
     if p and "pmc" in p:
         f = p["pmc"]["fetch"]["FETCH_SIZE"]["mean_per_dispatch"] * 1024 * 2      # KiB, doubled per the gfx950 calibration (MI355X_MICROARCH.md)
         w = p["pmc"]["write"]["WRITE_SIZE"]["mean_per_dispatch"] * 1024
-        ent.update(hbm_bytes_per_launch=f + w, fetch_bytes=f, write_bytes=w, traffic_from="profiles/%s_rocprof_summary.json" % tag.replace("default", "pmc"))
-        hashes.add(p.get("source_hash"))
         steps = n * ent["steps_per_launch"]
-        print("traffic per env-step: %.1f B (fetch %.1f, write %.1f)" % ((f + w) / steps, f / steps, w / steps))
+        ent.update(hbm_bytes_per_launch=f + w, fetch_bytes=f, write_bytes=w, hbm_bytes_per_env_step=(f + w) / steps,
+                   traffic_from="profiles/%s_rocprof_summary.json" % ptag)
+        hashes.add(p.get("source_hash"))
+        print("%s %d envs: traffic per env-step %.1f B (fetch %.1f, write %.1f); %.3f us per step" % (
+            conf, n, (f + w) / steps, f / steps, w / steps, ent["rocprofv3_avg_kernel_us"] / ent["steps_per_launch"]))
     cur["kernels"]["%s/%s/%d" % (short(t["kernel"]), conf, n)] = ent
 if len(hashes) == 1:
     cur["source_hash"] = hashes.pop()

@@ -34,5 +34,29 @@ sq)
   rocprofv3 --kernel-trace --pmc $C --output-format csv -d $RAW/q1 -- python3 bench.py $A $B > /dev/null
   python3 profiles/summarize.py r03_sq_n4096 $RAW/q0 --kernel $K --out $OUT --grid 16384 --cut 1024 --pmc sq=$RAW/q1
   ;;
+c25)
+  # configs 2 and 5 at their BASELINE sizes through their fragment kernels: duration + HBM-side traffic
+  export QD_BENCH_RAMP_STEPS=2048
+  A="--steps 2048 --warmup 1024"
+  for cfg in "config5 8192 k_rollout_coop 32768" "config2 4096 k_rollout< 4096"; do
+    set -- $cfg
+    rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${1}t -- python3 bench.py --config $1 --envs $2 $A $B > $OUT/bench_${1}_profiled.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/${1}f -- python3 bench.py --config $1 --envs $2 $A $B > /dev/null
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/${1}w -- python3 bench.py --config $1 --envs $2 $A $B > /dev/null
+    python3 profiles/summarize.py r03_pmc_${1}_n$2 $RAW/${1}t --kernel "$3" --out $OUT --grid $4 --cut 1024 --pmc fetch=$RAW/${1}f --pmc write=$RAW/${1}w
+  done
+  ;;
+big)
+  # 2^20 envs, 64-step fragments: configs 3, 5 (k_rollout_coop, 4 x 2^20 threads) and 2 (k_rollout, 2^20 threads)
+  export QD_BENCH_RAMP_STEPS=64
+  A="--envs 1048576 --fragment 64 --steps 128 --warmup 64"
+  for cfg in "config3 k_rollout_coop 4194304" "config5 k_rollout_coop 4194304" "config2 k_rollout< 1048576"; do
+    set -- $cfg
+    rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${1}bt -- python3 bench.py --config $1 $A $B > $OUT/bench_${1}_n1m_profiled.json
+    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/${1}bf -- python3 bench.py --config $1 $A $B > /dev/null
+    rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/${1}bw -- python3 bench.py --config $1 $A $B > /dev/null
+    python3 profiles/summarize.py r03_pmc_${1}_n1048576 $RAW/${1}bt --kernel "$2" --out $OUT --grid $3 --cut 64 --longest 64 --pmc fetch=$RAW/${1}bf --pmc write=$RAW/${1}bw
+  done
+  ;;
 esac
 ls -la $OUT
