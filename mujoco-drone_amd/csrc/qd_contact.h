@@ -35,7 +35,9 @@ struct ContactSet {
 };
 
 // centre c, orientation columns of Rg (row-major 3 x 3), half sizes
-QD_HD void contact_box(ContactSet& cs, const double c[3], const double Rg[9], double sx, double sy, double sz) {
+// CS: anything with push(x, y, z, dist) -- the per-lane ContactSet here, the counting / LDS sinks of qd_contact_group.h
+template <class CS>
+QD_HD void contact_box(CS& cs, const double c[3], const double Rg[9], double sx, double sy, double sz) {
   int n = 0;
   for (int i = 0; i < 8 && n < 4; i++) {
     const double vx = (i & 1) ? sx : -sx, vy = (i & 2) ? sy : -sy, vz = (i & 4) ? sz : -sz;
@@ -47,7 +49,8 @@ QD_HD void contact_box(ContactSet& cs, const double c[3], const double Rg[9], do
   }
 }
 
-QD_HD void contact_cylinder(ContactSet& cs, const double c[3], const double Rg[9], double radius, double hh) {
+template <class CS>
+QD_HD void contact_cylinder(CS& cs, const double c[3], const double Rg[9], double radius, double hh) {
   double ax = Rg[2], ay = Rg[5], az = Rg[8];
   double prjaxis = az;
   if (prjaxis > 0.0) { ax = -ax; ay = -ay; az = -az; prjaxis = -prjaxis; }

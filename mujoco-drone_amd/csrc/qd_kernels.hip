@@ -74,12 +74,8 @@ __device__ __forceinline__ void env_step(const KArgs& a, int i, EnvRegs& e, floa
   float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
   if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
   c0 = qclamp(c0, 0.f, 1.f); c1 = qclamp(c1, 0.f, 1.f); c2 = qclamp(c2, 0.f, 1.f); c3 = qclamp(c3, 0.f, 1.f);
-  if constexpr (SPEC == SPEC_FLOOR) {
-    // float64 raw parameter planes: the geom sizes are %.5g-rounded from them
-    const double arm_len = a.raw[(size_t)1 * a.npad + i], pend_len = LOAD ? a.raw[(size_t)4 * a.npad + i] : 0.0,
-                 weight_mass = LOAD ? a.raw[(size_t)5 * a.npad + i] : 0.0;
-    for (int k = 0; k < a.frame_skip; k++) e.acc = substep_floor<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h, arm_len, pend_len, weight_mass);
-  } else if (spec_frame_skip<SPEC>() == 1) {
+  static_assert(SPEC != SPEC_FLOOR, "floor-contact configurations are stepped by k_step_floor (qd_step_floor.hip)");
+  if (spec_frame_skip<SPEC>() == 1) {
     e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
   } else if (spec_frame_skip<SPEC>() == 2) {
     e.acc = substep<float, LOAD>(e.M, e.s, c0, c1, c2, c3, a.h);
@@ -1303,15 +1299,18 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
       if (env->spec == SPEC_RMA) L(true, SPEC_RMA);                          \
       else if (env->spec == SPEC_LSTM) L(true, SPEC_LSTM);                   \
       else if (env->spec == SPEC_GENERIC_FS1) L(true, SPEC_GENERIC_FS1);     \
-      else if (env->spec == SPEC_FLOOR) L(true, SPEC_FLOOR);                 \
       else L(true, SPEC_GENERIC);                                            \
     } else {                                                                 \
       if (env->spec == SPEC_SIMPLE) L(false, SPEC_SIMPLE);                   \
       else if (env->spec == SPEC_GENERIC_FS1) L(false, SPEC_GENERIC_FS1);    \
-      else if (env->spec == SPEC_FLOOR) L(false, SPEC_FLOOR);                \
       else L(false, SPEC_GENERIC);                                           \
     }                                                                        \
   } while (0)
+  if (env->spec == SPEC_FLOOR) {
+    // the floor plane: the contact solve is a lane-group computation of the wavefront (k_step_floor, qd_step_floor.hip)
+    QD_HIP(launch_step_floor(k, env->load, actions, obs, reward, truncated, S(stream)));
+    return QD_OK;
+  }
   if (env->load && env->spec == SPEC_RMA && k.n <= qd_coop_max_envs()) {
     // small batches of train_PPO.py / train_RMA.py's configuration: three wavefronts per 64 envs (k_step_coop)
     KArgs kk = k;
@@ -1371,6 +1370,7 @@ const char* qd_step_kernel_name(const qd_env* env) {
   static const char* const spec_name[] = {"0", "1", "2", "3", "4", "5"};
   static thread_local char buf[64];
   const int n = env->ka.n;
+  if (env->spec == SPEC_FLOOR) return env->load ? "qd::k_step_floor<true>" : "qd::k_step_floor<false>";
   if (env->load && env->spec == SPEC_RMA && n <= qd_coop_max_envs()) return "qd::k_step_coop<1>";
   const bool wide = n >= qd_block_threshold();
   snprintf(buf, sizeof buf, "qd::%s<%s,%d,%s>", wide ? "k_step_wide" : "k_step", env->load ? "true" : "false", wide ? 256 : 64,

@@ -8,7 +8,7 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 from mujoco_drone_amd import _lib as L
 from mujoco_drone_amd.environments import _device as dev
 from test_gpu_parity import make_cfg, rand_raw
-n = 4096
+n = int(os.environ.get("QD_DIAG_ENVS", "4096"))
 rng = np.random.default_rng(0)
 for load in (False, True):
     for where in ("flight", "floor"):
@@ -19,17 +19,23 @@ for load in (False, True):
         env.set_params(raw)
         nq, nv = (9, 8) if load else (7, 6)
         qpos = np.zeros((n, nq)); qpos[:, 3] = 1
-        qpos[:, 2] = 50.0 if where == "flight" else (0.02 if not load else 0.3)
+        qpos[:, 2] = 1e5 if where == "flight" else (0.02 if not load else 0.3)      # (high enough to still be falling after the warm-up)
         if load and where == "floor":
             qpos[:, 7] = 1.2                      # tether swung aside so that the box lies on the floor next to the airframe's height
         env.set_state(qpos, np.zeros((n, nv)), np.zeros((n, 4)))
         a = torch.zeros((n, 4), device="cuda")
-        for _ in range(300):
-            env.step(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(200):
-            env.step(a)
-        e1.record(); torch.cuda.synchronize()
+        # a short burst finds the GPU in a low power state (the same kernel read 61 and 80 us per step in two runs whose in-kernel
+        # cycle counts differed by 15 % the other way): sustained load first, then the best of three timed runs
+        best = 1e9
+        for rep in range(4):
+            for _ in range(1500 if rep == 0 else 300):
+                env.step(a)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(300):
+                env.step(a)
+            e1.record(); torch.cuda.synchronize()
+            if rep:
+                best = min(best, e0.elapsed_time(e1) * 1000 / 300)
         z = env.get_state()[0][:, 2]
-        print("%-8s %-6s: %.1f us per step of %d envs (z mean %.3f)" % ("load" if load else "no load", where, e0.elapsed_time(e1) * 1000 / 200, n, float(z.mean())), flush=True)
+        print("%-8s %-6s: %.1f us per step of %d envs (z mean %.3f)" % ("load" if load else "no load", where, best, n, float(z.mean())), flush=True)
