@@ -38,7 +38,7 @@ for f in os.listdir(src):
 
 
 def short(name):     # "void qd::k_rollout_coop<1>(qd::KArgs, ...)" -> "qd::k_rollout_coop<1>"
-    name = name.split("(")[0].replace(", ", ",")
+    name = name.split("(")[0].replace(", ", ",").replace(",false>", ">")     # (the library's selector leaves the PID = false flag out)
     return name[5:] if name.startswith("void ") else name
 
 
