@@ -96,7 +96,8 @@ def build_library(force=False, verbose=False):
         return LIB
     extra = _extra_flags()
     tmp = LIB + ".tmp.%d" % os.getpid()
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc",
+    # (-parallel-jobs: the translation units compile side by side; not a code generation flag, so not part of the hash)
+    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-parallel-jobs=%d" % min(4, len(sources())),
            "-Wno-unused-result", *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="%s"' % source_hash(extra), *extra, "-o", tmp] + sources()
     if verbose:
         cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
@@ -117,7 +118,7 @@ def build_variant(name, flags=()):
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "libqd_%s.so" % name)
     cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-           *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="variant:%s"' % name, *flags, "-o", out] + sources()
+           "-parallel-jobs=%d" % min(4, len(sources())), *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="variant:%s"' % name, *flags, "-o", out] + sources()
     subprocess.check_call(cmd)
     return out
 
