@@ -617,6 +617,8 @@ __device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRe
 hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream,
                                bool pid = false, float* actions_out = nullptr);
 
+// SimpleDrone's fragments at small batches: a physics wave and an epilogue wave per 64 envs (qd_rollout_coop.hip)
+hipError_t launch_rollout_pair(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 // qd_step_floor.hip: one env step of a floor-contact configuration (SPEC_FLOOR), any batch size
 hipError_t launch_step_floor(const KArgs& k, bool load, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 

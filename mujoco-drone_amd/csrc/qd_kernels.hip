@@ -1353,6 +1353,12 @@ static bool qd_fragment_is_persistent(const qd_env* env) {
 // worth a split over waves, so a fragment runs in k_rollout -- one wavefront per 64 envs, state in registers, rows through the
 // wave's LDS tile.  Measured against the per-step launches (tests/diag_rollout_simple.py, BASELINE config 2): 1.57 / 3.51 us per
 // step at 4096 envs, 2.03 / 5.13 at 65536, 24.8 / 54.7 at 2^20 (4.2e10 env-steps/s).
+// SimpleDrone while every workgroup finds a CU of its own (<= 16384 envs): physics and epilogue in two wavefronts (k_rollout_pair);
+// above, the chip is full either way and the single wavefront of k_rollout issues fewer instructions in all.  QD_PAIR_MAX_ENVS.
+static bool qd_fragment_is_pair(const qd_env* env) {
+  static const int v = [] { const char* e = getenv("QD_PAIR_MAX_ENVS"); return e ? atoi(e) : 16384; }();
+  return qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && !env->load && env->spec == SPEC_SIMPLE && env->ka.n <= v;
+}
 static bool qd_fragment_is_rollout(const qd_env* env) {
   return qd_persistent() && env->opt[QD_OPT_PERSISTENT_FRAGMENTS] && !env->load && env->spec != SPEC_FLOOR;
 }
@@ -1379,6 +1385,7 @@ const char* qd_step_kernel_name(const qd_env* env) {
 }
 const char* qd_fragment_kernel_name(const qd_env* env) {
   if (!env) return "";
+  if (qd_fragment_is_pair(env)) return "qd::k_rollout_pair";
   if (qd_fragment_is_rollout(env)) {
     static thread_local char buf[64];
     snprintf(buf, sizeof buf, "qd::k_rollout<false,64,%d>", env->spec);
@@ -1492,6 +1499,10 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
   }
   if (qd_fragment_is_persistent(env)) {
     QD_HIP(launch_rollout_coop(k, env->spec, T, actions, obs, reward, truncated, S(stream)));
+    return QD_OK;
+  }
+  if (qd_fragment_is_pair(env)) {
+    QD_HIP(launch_rollout_pair(k, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
   const dim3 grid(blocks64(k.n)), block(64);

@@ -545,6 +545,90 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
   }
 }
 
+// ---- SimpleDrone (BASELINE config 1 / 2): two wavefronts per 64 envs -----------------------------------------------------------
+// The single-body step is ~440 vector instructions of physics (two substeps at 1 kHz, SimpleDrone.py:54-61) and ~300 of
+// epilogue (the 6-value observation: a quaternion to matrix and three inverse trigonometric functions, SimpleDrone.py:94-98; the
+// row's way out through LDS).  k_rollout runs both in one wavefront; here a PHYSICS wave integrates, decides termination and the
+// reward (both functions of the distance it has anyway) and publishes the state, and an EPILOGUE wave, one step behind, turns
+// the published state into the row and streams it out.  One barrier per step, the published state double-buffered.
+struct RpLds {
+  float4 st[2][2][64];   // [buffer][(pos, -) / (quat)][lane]: what simple_obs reads of an env
+  float tile[64 * 8];
+};
+
+__global__ __launch_bounds__(128) void k_rollout_pair(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
+                                                      float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
+  __shared__ RpLds L;
+  const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int base_env = blockIdx.x * 64;
+  const int i = base_env + lane;
+  const bool live = i < a.n;
+  const int il = live ? i : a.n - 1;
+  const int n = a.n;
+  if (role == 0) {
+    // ================================================================ physics
+    EnvRegs e;
+    load_env<false, false, false>(a, il, e);
+    const float4* actions4 = reinterpret_cast<const float4*>(actions);
+    float4 act_next = actions4[il];
+    for (int t = 0; t < T; t++) {
+      const float4 action = act_next;
+      if (t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];
+      if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, e.num_steps, e.ref);
+      const float c0 = qclamp(action.x, 0.f, 1.f), c1 = qclamp(action.y, 0.f, 1.f), c2 = qclamp(action.z, 0.f, 1.f), c3 = qclamp(action.w, 0.f, 1.f);
+      e.acc = substep<float, false>(e.M, e.s, c0, c1, c2, c3, a.h);
+      e.acc = substep<float, false>(e.M, e.s, c0, c1, c2, c3, a.h);
+      e.flags &= ~FLAG_ACC_STALE;
+      e.num_steps += 1;
+      // SimpleDrone.step: terminated = |pos - ref| > 0.5, reward = 0.1 - |pos - ref| (SimpleDrone.py:57-60)
+      const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+      const float d = qsqrt(dx * dx + dy * dy + dz * dz);
+      const bool tr = d > 0.5f;
+      if (live) {
+        __builtin_nontemporal_store(0.1f - d, reward_out + (size_t)t * n + i);
+        __builtin_nontemporal_store((uint8_t)(tr ? 1 : 0), trunc_out + (size_t)t * n + i);
+      }
+      if (a.auto_reset && tr) {
+        if (live) reset_in_step<false, true>(a, i, e);
+        if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, e.ref);
+      }
+      const int b = t & 1;
+      L.st[b][0][lane] = make_float4(e.s.px, e.s.py, e.s.pz, 0.f);
+      L.st[b][1][lane] = make_float4(e.s.qw, e.s.qx, e.s.qy, e.s.qz);
+      coop_barrier();
+    }
+    if (live) store_env(a, i, e);
+  } else {
+    // ================================================================ epilogue, one step behind
+    for (int t = 0; t <= T; t++) {
+      if (t >= 1) {
+        const int b = (t - 1) & 1;
+        const float4 p = L.st[b][0][lane], q = L.st[b][1][lane];
+        State<float> s;
+        s.px = p.x; s.py = p.y; s.pz = p.z; s.qw = q.x; s.qx = q.y; s.qy = q.z; s.qz = q.w;
+        float o[6];
+        simple_obs<float>(s, o);
+        float* row = L.tile + lane * 6;
+#pragma unroll
+        for (int k = 0; k < 6; k++) row[k] = o[k];
+        __builtin_amdgcn_wave_barrier();
+        flush_obs_any<SPEC_SIMPLE>(L.tile, obs + ((size_t)(t - 1) * n + base_env) * 6, min(64, n - base_env), 6);
+        __builtin_amdgcn_wave_barrier();
+      }
+      if (t < T) coop_barrier();
+    }
+  }
+}
+
+hipError_t launch_rollout_pair(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
+  KArgs kk = k;
+  kk.main_blocks = (k.n + 63) / 64;
+  (void)hipGetLastError();
+  hipLaunchKernelGGL(k_rollout_pair, dim3(kk.main_blocks), dim3(128), 0, stream, kk, T, actions, obs, reward, trunc);
+  return hipGetLastError();
+}
+
 hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream,
                                bool pid, float* actions_out) {
   KArgs kk = k;

@@ -425,8 +425,8 @@ def test_config5_full_size_fragment_vs_oracle_200_steps(qd, orc):
 
 # ------------------------------------------------------------------ the single-body model: fragments run in k_rollout
 def test_config2_full_size_fragment_vs_oracle_and_per_step(qd, orc):
-    """BASELINE config 2 at its full size through qd_step_fragment (k_rollout<false,64,SPEC_SIMPLE>: one wavefront per 64 envs keeps
-    the state in registers for the whole fragment): 4096 SimpleDrone envs, fixed initial state, 200 steps of U[0.5, 1) rotor
+    """BASELINE config 2 at its full size through qd_step_fragment (k_rollout_pair: a physics wavefront and an epilogue wavefront per
+    64 envs, the state in registers for the whole fragment): 4096 SimpleDrone envs, fixed initial state, 200 steps of U[0.5, 1) rotor
     actions as four 50-step fragments; every env against the float64 oracle (<= 1e-4 relative), every step's rows, rewards and
     flags against the oracle's and against the per-step kernel's"""
     rng = np.random.default_rng(321)
@@ -434,7 +434,7 @@ def test_config2_full_size_fragment_vs_oracle_and_per_step(qd, orc):
     c = make_cfg(L, n, load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, h=0.001, ctrl_map=0, term=1,
                  ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0), max_steps=10 ** 6, max_distance=1e9)
     env, per = qd.dev.DeviceEnv(c), qd.dev.DeviceEnv(c)
-    assert env.fragment_kernel_name() == "qd::k_rollout<false,64,3>", env.fragment_kernel_name()
+    assert env.fragment_kernel_name() == "qd::k_rollout_pair", env.fragment_kernel_name()   # (<= 16384 envs; k_rollout<false,64,3> above)
     raw = np.tile([1.35, 0.15, 7.5, 0.015, 0, 0], (n, 1))
     q0 = np.tile([0, 0, 1, 1, 0, 0, 0.0], (n, 1))
     for e in (env, per):
@@ -467,10 +467,12 @@ def test_config2_full_size_fragment_vs_oracle_and_per_step(qd, orc):
     assert err < 1e-4 and wo < 2e-4 and wr < 2e-4 and wp < 2e-5
 
 
-def test_simple_drone_fragments_with_resets(qd):
+@pytest.mark.parametrize("n", [300, 20000])
+def test_simple_drone_fragments_with_resets(qd, n):
     """SimpleDrone.reset_model sampling inside a fragment (QD_START_SIMPLE: qpos0 + U(-0.03, 0.03), only drone 0 moved to start_pos)
-    and the BaseDroneEnv observation variants on the single-body model: fragments equal per-step launches"""
-    L, n, T = qd._lib, 300, 40
+    and the BaseDroneEnv observation variants on the single-body model: fragments equal per-step launches -- the two-wavefront
+    kernel (<= 16384 envs) and the single-wavefront one above"""
+    L, T = qd._lib, 40
     cases = [dict(load=False, obs="SimpleDrone", reward="simple_drone_reward", frame_skip=2, h=0.001, ctrl_map=0, term=1,
                   ref=(0, 0, 1, 0), start_pos=(0, 0, 1, 0), start=2, auto_reset=1, max_steps=9, max_distance=4.0),
              dict(load=False, obs="LocalFrameRPYEnv", reward="distance_energy_reward", start=1, random_params=1, auto_reset=1, max_steps=9)]
@@ -478,7 +480,8 @@ def test_simple_drone_fragments_with_resets(qd):
         mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, seed=4, **kw))
         a, b = mk(), mk()
         a.reset(); b.reset()
-        assert "k_rollout<false" in a.fragment_kernel_name()
+        assert a.fragment_kernel_name() == ("qd::k_rollout_pair" if (kw["obs"] == "SimpleDrone" and n <= 16384) else
+                                            "qd::k_rollout<false,64,%d>" % (3 if kw["obs"] == "SimpleDrone" else 4)), a.fragment_kernel_name()
         lo = 0.5 if kw["obs"] == "SimpleDrone" else 0.0
         for rep in range(2):
             acts = lo + (1 - lo) * torch.rand((T, n, 4), device="cuda")
