@@ -277,3 +277,33 @@ def test_policy_rollout_on_a_floor_env():
         if t in (0, 30, T - 1):
             np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), rtol=3e-4, atol=3e-4, err_msg="t=%d" % t)
     assert bool(torch.isfinite(out["obs"]).all())
+
+
+@pytest.mark.parametrize("load", [False, True])
+def test_lane_group_solver_is_batch_invariant_and_ragged(qd, load):
+    """k_step_floor steps 32 envs per workgroup and solves contacts 8 envs per wavefront with 8 lanes each: env i's trajectory must
+    not depend on where it sits -- a ragged batch (77 envs: a last workgroup with 13 envs, a last pass with 5) against the same
+    envs in a batch of 9 and alone, bit for bit, through impacts, rest, in-kernel resets (short episodes) and the reset pool's
+    sampler workgroups"""
+    L = qd._lib
+    kw = dict(load=load, obs="BaseDroneEnv", reward="default_reward_fcn", frame_skip=2, h=0.001, ctrl_map=0, max_steps=60,
+              max_distance=1e9, ref=(0, 0, 0.1, 0), start_pos=(0, 0, 0.35 if load else 0.08, 0), start=1, auto_reset=1, random_params=1,
+              seed=5, sdiff=0.05)
+    envs = []
+    for n in (77, 9, 1):
+        c = make_cfg(L, n, **kw)
+        c.floor_contact = 1
+        e = qd.dev.DeviceEnv(c)
+        e.reset()
+        envs.append(e)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    touched = 0
+    for t in range(150):
+        a = 0.3 * torch.rand((77, 4), generator=g, device="cuda")      # weak rotors: everybody comes down
+        outs = [e.step(a[:e.n].contiguous()) for e in envs]
+        for (o, r, tr), e in zip(outs[1:], envs[1:]):
+            assert torch.equal(outs[0][0][:e.n], o) and torch.equal(outs[0][1][:e.n], r) and torch.equal(outs[0][2][:e.n], tr), (t, e.n)
+        touched += int((envs[0].get_state()[0][:, 2] < (1.6 if load else 0.05)).sum())     # (with the load: its box or the rod is down)
+    for x, y in zip(envs[0].get_state(), envs[1].get_state()):
+        assert torch.equal(x[:9], y)
+    assert touched > 77 * 20 and torch.isfinite(outs[0][0]).all()

@@ -494,3 +494,39 @@ def test_simple_drone_fragments_with_resets(qd, n):
                 d[:, 3:6] = torch.minimum(d[:, 3:6], (d[:, 3:6] - 2 * np.pi).abs())
                 assert float(d.max()) <= 2e-5 and float((R[t] - r).abs().max()) <= 2e-5, (kw["obs"], rep, t, float(d.max()))
         assert int(Tr.sum()) > 0
+
+
+def test_generic_and_pid_instantiations_at_two_workgroups_per_cu(qd):
+    """the register-capped (OCC = 2) instantiations of the run-time-dispatched kernel and of the PID-driven sensor-carrying kernel,
+    which only run above 16384 envs: against the per-step launches on the first envs of a 20 000-env batch"""
+    L, n, T = qd._lib, 20000, 24
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs="LocalFramePRYaccEnv", reward="reward_1", start=1, random_params=1,
+                                             auto_reset=1, max_steps=8, seed=23))
+    a, b = mk(), mk()
+    a.reset(); b.reset()
+    assert a.fragment_kernel_name() == "qd::k_rollout_coop<4,2>"
+    acts = torch.rand((T, n, 4), device="cuda")
+    O, R, Tr = _bufs(T, n, a.D)
+    a.step_fragment(acts, O, R, Tr)
+    for t in range(T):
+        o, r, tr = b.step(acts[t])
+        assert torch.equal(Tr[t], tr), t
+        d = _heading_safe_absdiff(O[t], o)
+        assert float(d[:, 12:15].max()) <= 3e-3, (t, float(d[:, 12:15].max()))
+        d[:, 12:15] = 0
+        assert float(d.max()) <= 1e-4 and float((R[t] - r).abs().max()) <= 1e-3, (t, float(d.max()))
+    # the PID cascade on train_LSTM.py's configuration (sensor-carrying rows, circle waypoints), persistent against launch by launch
+    import bench
+    e1, _ = bench.make_env("config5", n, 42, "cuda:0")
+    e2, _ = bench.make_env("config5", n, 42, "cuda:0")
+    e2._dev.set_option(L.OPT_PERSISTENT_FRAGMENTS, 0)
+    e1.vector_reset_tensor(); e2.vector_reset_tensor()
+    e1.pid_reset(); e2.pid_reset()
+    o1, r1, t1, a1 = e1.rollout_pid_tensor(40, want_actions=True)
+    o2, r2, t2, a2 = e2.rollout_pid_tensor(40, want_actions=True)
+    assert torch.equal(t1, t2)
+    assert float((a1 - a2).abs().max()) <= 2e-4 and float((r1 - r2).abs().max()) <= 2e-3
+    d = _heading_safe_absdiff(o1, o2)
+    assert float(d[..., 12:15].max()) <= 5e-3
+    d[..., 12:15] = 0
+    assert float(d.max()) <= 3e-4, float(d.max())
