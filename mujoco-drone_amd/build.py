@@ -26,6 +26,11 @@ ARCH = "gfx950"
 # the step kernels' leading scalar arguments arrive in SGPRs at wave launch instead of through a kernarg fetch at the top of the
 # kernel (csrc/qd_kernels.hip, StepKernarg); part of the source hash like the sources themselves
 CODEGEN_FLAGS = ("-mllvm", "-amdgpu-kernarg-preload-count=5")
+# per translation unit, on top of CODEGEN_FLAGS (part of the source hash too).  qd_rollout_coop.hip: the SLP vectoriser packs the
+# float32 3-vector arithmetic of the applied wrench into v_pk_*_f32 pairs and pays for every pair with a register move -- in the
+# issue-bound waves of the persistent kernel that is a loss (same box, alternating runs: 1.485 -> 1.347 us per step at 4096 envs,
+# config 5 at 8192 envs 1.946 -> 1.847); the per-step kernels of qd_kernels.hip measured the other way in round 2 and keep it.
+UNIT_FLAGS = {"qd_rollout_coop.hip": ("-fno-slp-vectorize",)}
 HASH_TAG = b"QD_SOURCE_HASH="
 
 
@@ -58,6 +63,8 @@ def source_hash(extra_flags=()):
         h.update(open(d, "rb").read())
         h.update(b"\0")
     h.update(" ".join(CODEGEN_FLAGS + tuple(extra_flags)).encode())
+    for unit in sorted(UNIT_FLAGS):
+        h.update(("%s:%s" % (unit, " ".join(UNIT_FLAGS[unit]))).encode())
     return h.hexdigest()
 
 
@@ -90,20 +97,35 @@ def needs_build():
     return embedded_hash() != source_hash(_extra_flags())
 
 
+def _compile_and_link(out, hash_define, flags, verbose=False):
+    """every translation unit to an object with its own flags (side by side), then one link"""
+    import tempfile
+    hip = _hipcc()
+    common = [hip, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", *CODEGEN_FLAGS, hash_define, *flags]
+    with tempfile.TemporaryDirectory(prefix="qd_build_") as tmpdir:
+        procs, objs = [], []
+        for src in sources():
+            obj = os.path.join(tmpdir, os.path.basename(src) + ".o")
+            cmd = common + list(UNIT_FLAGS.get(os.path.basename(src), ())) + ["-c", src, "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+                print(" ".join(cmd), flush=True)
+            procs.append((cmd, subprocess.Popen(cmd)))
+            objs.append(obj)
+        for cmd, p in procs:
+            if p.wait() != 0:
+                raise subprocess.CalledProcessError(p.returncode, cmd)
+        subprocess.check_call([hip, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs)
+
+
 def build_library(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libqd.so next to this file (only if the sources changed, unless forced)."""
     if not force and not needs_build():
         return LIB
     extra = _extra_flags()
     tmp = LIB + ".tmp.%d" % os.getpid()
-    # (-parallel-jobs: the translation units compile side by side; not a code generation flag, so not part of the hash)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-parallel-jobs=%d" % min(4, len(sources())),
-           "-Wno-unused-result", *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="%s"' % source_hash(extra), *extra, "-o", tmp] + sources()
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd), flush=True)
     try:
-        subprocess.check_call(cmd)
+        _compile_and_link(tmp, '-DQD_SOURCE_HASH="%s"' % source_hash(extra), extra, verbose)
         os.replace(tmp, LIB)   # atomic: a process that has the old file mapped keeps its copy
     finally:
         if os.path.exists(tmp):
@@ -117,9 +139,7 @@ def build_variant(name, flags=()):
     out_dir = os.path.join(os.path.dirname(PKG_DIR), "tests", "_build")
     os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, "libqd_%s.so" % name)
-    cmd = [_hipcc(), "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result",
-           "-parallel-jobs=%d" % min(4, len(sources())), *CODEGEN_FLAGS, '-DQD_SOURCE_HASH="variant:%s"' % name, *flags, "-o", out] + sources()
-    subprocess.check_call(cmd)
+    _compile_and_link(out, '-DQD_SOURCE_HASH="variant:%s"' % name, list(flags))
     return out
 
 

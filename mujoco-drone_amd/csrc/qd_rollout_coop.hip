@@ -41,6 +41,9 @@
 namespace qd {
 
 constexpr int RC_THREADS = 256;
+#ifndef RC_PRE
+#define RC_PRE true
+#endif
 
 struct RcLds {
   float4 app[5][64];      // B -> A: Applied (F, t1) (Tq, t2) and the attitude matrix
@@ -126,7 +129,7 @@ __device__ __forceinline__ int rc_acc_slot(int kind) {
 __device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rhs<double>& r, const M3<float>& R, V3<float> w0) {
   Accel<float> ex;
   V3<double> a0ex;
-  finish_accel<false>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+  finish_accel<false, RC_PRE>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
   const float g = float(Const::gravity);
   return accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
                        mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
@@ -217,7 +220,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       const float4 action = act_next;
       if (!PID && t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
-      f = mass_factor(e.M, tg, a.h);
+      f = mass_factor<RC_PRE>(e.M, tg, a.h);
       auto filter = [&](float4 u) {   // ctrl map and the activation filter: the part of the Euler step that does not wait for the accelerations
         float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
         if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
@@ -228,9 +231,14 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
       // arithmetic across freely, and left alone it sinks two thirds of the factorisation into phase 2 -- onto the critical
       // path, while this wave sits at the barrier waiting for the applied wrench (stamps: phase 2 2600 cycles instead of 1800)
-      rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc); rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
-      rc_pin(f.s11, f.s12, f.s22); rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
-      rc_pin(f.imt, f.m2, f.hb);
+      rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc);
+      rc_pin(f.s11, f.s12, f.s22); rc_pin(f.imt, f.m2, f.hb);
+      if constexpr (RC_PRE) {
+        rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
+        rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
+      } else {
+        rc_pin(f.S); rc_pin(f.p1); rc_pin(f.p2); rc_pin(f.d0, f.d1, f.d2); rc_pin(f.l10, f.l20, f.l21);
+      }
       asm volatile("" ::"v"(e.s.a0), "v"(e.s.a1), "v"(e.s.a2), "v"(e.s.a3), "v"(e.ref[0]), "v"(e.ref[1]), "v"(e.ref[2]));
       RC_STAMP(1);
       coop_barrier();   // 1
@@ -249,14 +257,14 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
           const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
           in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
         }
-        r = reduce_rhs(f, ap, in);
+        r = reduce_rhs<RC_PRE>(f, ap, in);
       }
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
       if (!half) {
         if (PID) filter(L.act[lane]);   // wave C evaluated the controller on s_t during phase 1
         Accel<float> im;
         V3<double> a0im;
-        finish_accel<true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+        finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
         im.lin = mul(R, cvt<float>(a0im));
         integrate_motion<float, true>(e.s, im, a.h);
         e.flags &= ~FLAG_ACC_STALE;
