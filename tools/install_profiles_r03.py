@@ -39,7 +39,7 @@ for f in os.listdir(src):
 
 def short(name):     # "void qd::k_rollout_coop<1>(qd::KArgs, ...)" -> "qd::k_rollout_coop<1>"
     name = name.split("(")[0].replace(", ", ",").replace(",false>", ">")     # (the library's selector leaves the PID = false flag out)
-    return name[5:] if name.startswith("void ") else name
+    return name[5:] if name.startswith("void ") else name   # (a plain kernel like qd::k_rollout_pair comes without the "void ")
 
 
 cur = {"_comment": "written by tools/install_profiles_r03.py from the rocprofv3 runs of tools/profile_r03.sh; bench.py quotes an entry only "

@@ -38,7 +38,7 @@ c25)
   # configs 2 and 5 at their BASELINE sizes through their fragment kernels: duration + HBM-side traffic
   export QD_BENCH_RAMP_STEPS=2048
   A="--steps 2048 --warmup 1024"
-  for cfg in "config5 8192 k_rollout_coop 32768" "config2 4096 k_rollout< 4096"; do
+  for cfg in "config5 8192 k_rollout_coop 32768" "config2 4096 k_rollout_pair 8192"; do
     set -- $cfg
     rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${1}t -- python3 bench.py --config $1 --envs $2 $A $B > $OUT/bench_${1}_profiled.json
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/${1}f -- python3 bench.py --config $1 --envs $2 $A $B > /dev/null
