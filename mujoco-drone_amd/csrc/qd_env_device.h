@@ -611,6 +611,30 @@ __device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRe
   return make_float4(act[0], act[1], act[2], act[3]);
 }
 
+// ---- pieces the persistent role kernels share (qd_rollout_coop.hip, qd_rollout_fused.hip) ----
+#ifndef RC_PRE
+#define RC_PRE true
+#endif
+// the env's reference at episode step k (static: `base`, fetched once)
+__device__ __forceinline__ void rc_ref(const KArgs& a, int i, int k, const float base[4], float ref[4]) {
+  if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, k, ref);
+  else { ref[0] = base[0]; ref[1] = base[1]; ref[2] = base[2]; ref[3] = base[3]; }
+}
+// "this value exists here": an empty asm that reads it (the volatile asms keep their order, the barrier among them)
+__device__ __forceinline__ void rc_pin(double x, double y, double z) { asm volatile("" ::"v"(x), "v"(y), "v"(z)); }
+__device__ __forceinline__ void rc_pin(const V3<double>& v) { rc_pin(v.x, v.y, v.z); }
+
+// the accelerometer reading of a step from its factor and right-hand side (what k_step_coop's phase 3 computes)
+__device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rhs<double>& r, const M3<float>& R, V3<float> w0) {
+  Accel<float> ex;
+  V3<double> a0ex;
+  finish_accel<false, RC_PRE>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+  const float g = float(Const::gravity);
+  return accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                       mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+}
+
+
 // qd_rollout_coop.hip: T steps of the load model (SPEC_RMA, SPEC_LSTM or SPEC_GENERIC_FS1: one substep per step) in ONE launch,
 // four wavefronts per 64 envs.  `k` as qd_step would pass it (main_blocks is set by the launcher).
 // `pid`: the analytic PID cascade (qd_pid.h) is the action source (actions = nullptr, actions_out [T,N,4] nullable), else `actions` [T,N,4].

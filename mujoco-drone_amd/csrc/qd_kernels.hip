@@ -608,6 +608,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
   constexpr bool has_value = A::prog.value_buf >= 0;
   for (int t = 0; t < T; t++) {
     // ---- policy forward on the tiles ----
+    POL_STAMP(40);
     SLead<A, 0, LC> lead;
     lead.load(c);
     for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;  // the input buffers also held last step's outputs
@@ -616,7 +617,9 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
     if (CONST_OPS && t > 0)  // z of step 0 back into its slice of the input buffer (cleared above); the encoder ops are skipped
       for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
     __syncthreads();
+    POL_STAMP(41);
     s_run<A, LC, J0>(c, pre);
+    POL_STAMP(42);
     if (CONST_OPS && t == 0) {  // the embedding is final once the program has run: keep it for the rest of the fragment
       for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) ztile[k] = lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)];
       c.skip_ops = CONST_OPS;
@@ -628,6 +631,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
     pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
                 logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
     __syncthreads();
+    POL_STAMP(43);
     // ---- env step: wave 0, one env per lane ----
     if (wave == 0) {
       if (envlane) {
@@ -635,10 +639,12 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
         // the policy phase as k_rollout does would add ~70 live registers to the MFMA code
         fused_env_phase<LOAD, SPEC>(a, i, atile + lane * 4, otile + lane * D, reward + (size_t)t * n + i, trunc + (size_t)t * n + i, trt + lane);
       }
+      POL_STAMP(44);
       __builtin_amdgcn_wave_barrier();
       for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
     }
     __syncthreads();
+    POL_STAMP(45);
   }
 }
 

@@ -63,7 +63,7 @@ struct PolArgs {
 
 typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef QD_STAMPS
+#if defined(QD_STAMPS) && !defined(QD_POL_SECOND_UNIT)
 // diagnostic build only: s_memrealtime (100 MHz) stamps of wave 0 of workgroup 0 after every op's barrier
 __device__ unsigned long long qd_pstamps[64];
 #define POL_STAMP(k)                                                                                                  \
@@ -155,6 +155,7 @@ __device__ __forceinline__ void pol_mac(const PolStep& s, const PolBuf& w, const
   }
 }
 
+#ifndef QD_POL_SECOND_UNIT   // the two non-template kernels live in ONE translation unit (qd_kernels.hip)
 // qd_policy_reset_state: every ring slot of the selected envs <- the ring's episode-start values (read from the blob)
 __global__ __launch_bounds__(256) void k_policy_reset_state(PolArgs p, float* __restrict__ state, int n_envs, const uint8_t* __restrict__ mask) {
   const float* small = p.packed + p.prog_ints;
@@ -321,5 +322,6 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy(PolArgs p, int n_envs, c
   pol_outputs(lds + p.logits_lds, p.ld_logits, p.n_logits, p.act_dim, env0, n_envs, tid, lds + p.act_floats - POL_SCRATCH, smp, actions, logp, logits, nullptr, p.dist);
   POL_STAMP(2 + p.n_ops);
 }
+#endif  // QD_POL_SECOND_UNIT
 
 }  // namespace qd

@@ -267,10 +267,10 @@ struct ArchDsnLstm {  // DSN_LSTM_model (mujoco_drone_amd/policy.py; table print
 // Ops whose result depends on the drone parameters only (the parameter encoder of the RMA networks, writing the auxiliary slice z):
 // within one fused rollout the parameters of an env do not change (in-kernel resets keep them; regeneration is a host call
 // between fragments), so k_rollout_fused runs them on the first step only and keeps z in LDS.
-template <class A> constexpr unsigned fused_const_ops = 0u;
-template <> constexpr unsigned fused_const_ops<ArchRmaFull> = (1u << 3) | (1u << 4);
-template <> constexpr unsigned fused_const_ops<ArchRmaModel> = (1u << 3) | (1u << 4);
-template <> constexpr unsigned fused_const_ops<ArchRmaSmaller> = (1u << 3) | (1u << 4);
+template <class A> inline constexpr unsigned fused_const_ops = 0u;
+template <> inline constexpr unsigned fused_const_ops<ArchRmaFull> = (1u << 3) | (1u << 4);
+template <> inline constexpr unsigned fused_const_ops<ArchRmaModel> = (1u << 3) | (1u << 4);
+template <> inline constexpr unsigned fused_const_ops<ArchRmaSmaller> = (1u << 3) | (1u << 4);
 
 // ---- the specialised kernel ----
 struct SCtx {
@@ -619,6 +619,14 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   pol_outputs(lds + lg_base, ldl, NL, AD, c.env0, n_envs, c.tid, lds + ACT - POL_SCRATCH, smp, actions, logp, logits, nullptr, p.dist);
   POL_STAMP(2 + A::prog.n_ops);
 }
+
+// qd_rollout_fused.hip: the closed policy -> env loop of one fragment in one launch, the env step beside the forward pass (load
+// model, SPEC_RMA rows, the feed-forward 22-value networks: arch ids 1, 2, 7, 9; hipErrorNotSupported for any other).
+// `lds_bytes`: the policy's dynamic LDS (qd_policy_create).  `k` as qd_step would pass it.
+struct KArgs;
+hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa, size_t lds_bytes, int T, const PolSample& smp,
+                                     const float* obs0, const float* prev0, float* obs, float* actions, float* reward, uint8_t* trunc,
+                                     float* logp, float* logits, float* value, hipStream_t stream);
 
 // ---- host: does a program handed to qd_policy_create equal one of the tables above? ----
 template <class A>

@@ -41,9 +41,6 @@
 namespace qd {
 
 constexpr int RC_THREADS = 256;
-#ifndef RC_PRE
-#define RC_PRE true
-#endif
 
 struct RcLds {
   float4 app[5][64];      // B -> A: Applied (F, t1) (Tq, t2) and the attitude matrix
@@ -77,11 +74,6 @@ __device__ __forceinline__ void rc_get_state(const float4 (*st)[64], int lane, S
   s.a0 = c.x; s.a1 = c.y; s.a2 = c.z; s.a3 = c.w;
   s.thd2 = x.x;
 }
-// the env's reference at episode step k (static: `base`, fetched once)
-__device__ __forceinline__ void rc_ref(const KArgs& a, int i, int k, const float base[4], float ref[4]) {
-  if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, k, ref);
-  else { ref[0] = base[0]; ref[1] = base[1]; ref[2] = base[2]; ref[3] = base[3]; }
-}
 // a pre-sampled initial state into one slot of the LDS pool, planes and tag as pool_store() writes them to the arena
 __device__ __forceinline__ void pool_put_lds(float4 (*slot)[64], int lane, uint32_t episode, const State<float>& s) {
   slot[0][lane] = make_float4(s.px, s.py, s.pz, s.th1);
@@ -93,10 +85,6 @@ __device__ __forceinline__ void pool_put_lds(float4 (*slot)[64], int lane, uint3
 __device__ __forceinline__ bool rc_entry_valid(float4 tagp, uint32_t episode) {
   return __float_as_uint(tagp.z) != 0u && __float_as_uint(tagp.y) == episode;
 }
-
-// "this value exists here": an empty asm that reads it (the volatile asms keep their order, the barrier among them)
-__device__ __forceinline__ void rc_pin(double x, double y, double z) { asm volatile("" ::"v"(x), "v"(y), "v"(z)); }
-__device__ __forceinline__ void rc_pin(const V3<double>& v) { rc_pin(v.x, v.y, v.z); }
 
 #ifdef QD_STAMPS
 // diagnostic build: cycle stamps of one step in the middle of the fragment, 16 per (workgroup, wave)
@@ -125,16 +113,6 @@ __device__ __forceinline__ int rc_acc_slot(int kind) {
     default: return -1;
   }
 }
-// the accelerometer reading of a step from its factor and right-hand side (what k_step_coop's phase 3 computes)
-__device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rhs<double>& r, const M3<float>& R, V3<float> w0) {
-  Accel<float> ex;
-  V3<double> a0ex;
-  finish_accel<false, RC_PRE>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
-  const float g = float(Const::gravity);
-  return accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
-                       mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
-}
-
 // SPEC_RMA (train_PPO.py / train_RMA.py), SPEC_LSTM (train_LSTM.py) or SPEC_GENERIC_FS1 (any observation / reward of the load
 // model, dispatched at run time in wave D), all with skip_steps = 1.
 //

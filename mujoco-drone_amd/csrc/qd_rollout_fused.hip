@@ -1,0 +1,449 @@
+// qd_rollout_fused.hip -- the closed policy -> env loop (rollout.py:64-85 / the sampler's fragments) with the env step
+// running BESIDE the forward pass instead of after it.
+//
+// What makes that possible is in the model, not in the kernel: the motors are first-order filters (dyntype filter, env_gen.py), so
+// the force of step t comes from the activations a_t, and the action u_t only enters the activations of the NEXT state,
+// a_{t+1} = a_t + h (clamp(u_t) - a_t) / tau.  Position, attitude, velocities and hinge angles of s_{t+1} -- everything an
+// observation row of the sensor-free variants reads -- do not depend on u_t at all, and neither does the truncation test; only
+// the reward (its energy term) and the four activations do.  So while waves 0..3 of a workgroup run the network on observation
+// o_t (k_policy_static's code: float32 MFMA, activations in LDS), waves 4..7 advance the same 16 envs from s_t to s_{t+1} in the
+// roles of k_rollout_coop (A factorisation / solve / integration / resets, B applied wrench, C inertial wrench, D observation
+// row), 16 lanes each, and have o_{t+1} in LDS long before the network has u_t.  When it has, wave A applies the filter, wave D
+// evaluates the reward, and the next forward pass starts at once: a step costs the forward pass, not forward pass + env step
+// (k_rollout_fused, one wave of 16 lanes after the network: 11.8 us per step at 4096 envs, 3.6 of them the env phase).
+//
+// gfx950 has ONE barrier per workgroup, so the env waves pass exactly the barriers the network executes: two for the input
+// gathers, one per executed layer, one behind the outputs.  The three env stages sit in front of the first three layer barriers
+// (the layers behind them take 1.4 / 2.9 / 1.3 us for RMA_full, the stages 0.7 / 0.6 / 0.5), the rest are passed empty.
+// Arithmetic: the role functions of qd_dynamics.h on the same values as k_rollout_coop -- equal to the per-step kernels to
+// rounding (tests/test_gpu_policy.py compares with the two-launch loop).  Resets sample inline (a pure function of seed, env,
+// episode: the same states the pool would serve), inside the longest layer's window.
+#include <cstdlib>
+
+#define QD_POL_SECOND_UNIT
+#include "qd_env_device.h"
+#include "qd_policy_static.h"
+
+namespace qd {
+
+constexpr int FP_THREADS = 2 * POL_THREADS;   // waves 0..3 the network, waves 4..7 the env roles
+
+struct FpLds {                 // the env waves' hand-over: one column per env of the tile
+  float4 app[5][POL_TILE];     // B -> A: Applied (F, t1) (Tq, t2), the attitude matrix
+  double2 ine[4][POL_TILE];    // C -> A: Inertial (F, Tq, t1, t2)
+  float4 st[6][POL_TILE];      // A -> B, C, D: the state the next step starts from (rc_put_state's planes)
+  float4 pre[6][POL_TILE];     // A -> D: the state before the reset of a truncated lane (its reward is of this state)
+  uint4 info[POL_TILE];        // A -> D: (bit 0 truncated | bit 1 reset), episode counter, num_steps after the step, -
+};
+
+__device__ __forceinline__ void fp_put_state(float4 (*st)[POL_TILE], int lane, const State<float>& s) {
+  st[0][lane] = make_float4(s.px, s.py, s.pz, s.th1);
+  st[1][lane] = make_float4(s.qw, s.qx, s.qy, s.qz);
+  st[2][lane] = make_float4(s.vx, s.vy, s.vz, s.th2);
+  st[3][lane] = make_float4(s.wx, s.wy, s.wz, s.thd1);
+  st[4][lane] = make_float4(s.a0, s.a1, s.a2, s.a3);
+  st[5][lane] = make_float4(s.thd2, 0.f, 0.f, 0.f);
+}
+__device__ __forceinline__ void fp_get_state(const float4 (*st)[POL_TILE], int lane, State<float>& s) {
+  const float4 p = st[0][lane], q = st[1][lane], v = st[2][lane], w = st[3][lane], c = st[4][lane], x = st[5][lane];
+  s.px = p.x; s.py = p.y; s.pz = p.z; s.th1 = p.w;
+  s.qw = q.x; s.qx = q.y; s.qy = q.z; s.qz = q.w;
+  s.vx = v.x; s.vy = v.y; s.vz = v.z; s.th2 = v.w;
+  s.wx = w.x; s.wy = w.y; s.wz = w.z; s.thd1 = w.w;
+  s.a0 = c.x; s.a1 = c.y; s.a2 = c.z; s.a3 = c.w;
+  s.thd2 = x.x;
+}
+
+// the barriers s_run<A, LC, J0> executes in one pass: one per op that runs and is not folded into the layer before it
+template <class A, int I>
+__device__ __forceinline__ int fp_run_barriers_from(bool want_value, unsigned skip_ops) {
+  if constexpr (I < A::prog.n_ops) {
+    constexpr SOp op = A::prog.op[I];
+    constexpr bool folded = op.kind != POL_DENSE && I > 0 && sp_fused_affine(A::prog, I > 0 ? I - 1 : 0);
+    const bool runs = (want_value || !(op.flags & POL_FLAG_VALUE_ONLY)) && !((skip_ops >> I) & 1u);
+    return ((runs && !folded) ? 1 : 0) + fp_run_barriers_from<A, I + 1>(want_value, skip_ops);
+  } else {
+    return 0;
+  }
+}
+template <class A>
+__device__ __forceinline__ int fp_run_barriers(bool want_value, unsigned skip_ops) {
+  return fp_run_barriers_from<A, sp_leading_copies(A::prog)>(want_value, skip_ops);
+}
+template <class A>
+constexpr int fp_min_barriers() {   // actor only, parameter encoder skipped: the fewest a step can have
+  int nb = 0;
+  for (int I = sp_leading_copies(A::prog); I < A::prog.n_ops; I++) {
+    const bool runs = !(A::prog.op[I].flags & POL_FLAG_VALUE_ONLY) && !((fused_const_ops<A> >> I) & 1u);
+    const bool folded = A::prog.op[I].kind != POL_DENSE && I > 0 && sp_fused_affine(A::prog, I - 1);
+    if (runs && !folded) nb++;
+  }
+  return nb;
+}
+
+#ifdef QD_STAMPS
+// diagnostic build: s_memrealtime (10 ns) stamps of the last step, [0..15] network (thread 0), [16 + 8 role + k] the env waves
+__device__ unsigned long long qd_fpstamps[64];
+#define FP_STAMP(k)                                                                                     \
+  do {                                                                                                  \
+    if (blockIdx.x == 0 && lane == 0 && (k) < 64) qd_fpstamps[(k)] = __builtin_amdgcn_s_memrealtime();  \
+  } while (0)
+#else
+#define FP_STAMP(k)
+#endif
+
+template <int SPEC, class A>
+__global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolArgs p, int T, PolSample smp, const float* __restrict__ obs0,
+                                                                   const float* __restrict__ prev0, float* __restrict__ obs,
+                                                                   float* __restrict__ actions, float* __restrict__ reward,
+                                                                   uint8_t* __restrict__ trunc, float* __restrict__ logp,
+                                                                   float* __restrict__ logits, float* __restrict__ value) {
+  static_assert(SPEC == SPEC_RMA, "the observation row must not read the accelerometer or the activations");
+  static_assert(fp_min_barriers<A>() >= 3, "three layer barriers per step carry the three env stages");
+  extern __shared__ float lds[];
+  __shared__ FpLds L;
+  constexpr int ACT = sp_act_floats(A::prog), S4 = sp_small_floats(A::prog) / 4, SIT = (S4 + POL_THREADS - 1) / POL_THREADS;
+  constexpr int D = A::prog.obs_dim, AD = A::prog.act_dim, LC = sp_leading_copies(A::prog), J0 = sp_next_dense(A::prog, 0);
+  constexpr int IN_FLOATS = POL_TILE * (sp_ld(A::prog, 0) + sp_ld(A::prog, 1));  // buffers 0 and 1 take the gathered inputs
+  static_assert(D == spec_obs_dim<SPEC>() && AD == 4, "policy and env agree on the row");
+  float* small = lds + ACT;
+  float* otile = small + S4 * 4;           // [16][D] observation rows: obs0, then what the env waves' stage 3 wrote during the last pass
+  float* atile = otile + POL_TILE * D;     // [16][4] actions of the last pass (previous action of the next)
+  uint8_t* trt = reinterpret_cast<uint8_t*>(atile + POL_TILE * AD);  // [16] truncated flags of the last step
+  constexpr unsigned CONST_OPS = fused_const_ops<A>;
+  constexpr int ZD = CONST_OPS ? A::prog.aux_dim : 0;
+  float* ztile = atile + POL_TILE * AD + 16;   // [16][aux_dim] the parameter embedding of the first step
+  constexpr int z_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, z_ld = sp_ld(A::prog, A::prog.aux_buf);
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = tid & 63;
+  const int env0 = blockIdx.x * POL_TILE, rows = min(POL_TILE, a.n - env0), n = a.n;
+  const bool want_value = value != nullptr;
+
+  if (wave < POL_WAVES) {
+    // ==================================================================== waves 0..3: the network (k_rollout_fused's forward pass)
+    SCtx c;
+    c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
+    c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
+    c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
+    c.n_envs = rows; c.env0 = 0; c.want_value = want_value;
+    c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
+    c.skip_ops = 0u;
+    SPre<A, J0> pre;
+    s_prefetch<A, J0>(c, pre);
+    {  // prologue: parameters mirror, first observation / previous action, cleared activations
+      const float4* src = reinterpret_cast<const float4*>(p.packed + p.prog_ints);
+      float4 sm[SIT];
+#pragma unroll
+      for (int it = 0; it < SIT; it++) {
+        const int k = tid + it * POL_THREADS;
+        sm[it] = k < S4 ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
+      }
+      for (int k = tid; k < POL_TILE * D; k += POL_THREADS) otile[k] = k < rows * D ? obs0[(size_t)env0 * D + k] : 0.f;
+      for (int k = tid; k < POL_TILE * AD; k += POL_THREADS) atile[k] = (prev0 && k < rows * AD) ? prev0[(size_t)env0 * AD + k] : 0.f;
+      if (tid < POL_TILE) trt[tid] = 0;
+      for (int k = tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;
+      float4* dst = reinterpret_cast<float4*>(small);
+#pragma unroll
+      for (int it = 0; it < SIT; it++) {
+        const int k = tid + it * POL_THREADS;
+        if (k < S4) dst[k] = sm[it];
+      }
+    }
+    __syncthreads();   // P
+    constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits;
+    constexpr int lg_base = sp_base(A::prog, A::prog.logits_buf) + A::prog.logits_off;
+    constexpr int VB = A::prog.value_buf < 0 ? 0 : A::prog.value_buf;
+    constexpr int v_base = sp_base(A::prog, VB) + A::prog.value_off, v_ld = sp_ld(A::prog, VB);
+    constexpr bool has_value = A::prog.value_buf >= 0;
+    for (int t = 0; t < T; t++) {
+      FP_STAMP(0);
+      SLead<A, 0, LC> lead;
+      lead.load(c);
+      for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;  // the input buffers also held last step's outputs
+      __syncthreads();   // G0
+      lead.store(c);
+      if (CONST_OPS && t > 0)  // z of step 0 back into its slice of the input buffer (cleared above); the encoder ops are skipped
+        for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
+      __syncthreads();   // G1
+      FP_STAMP(1);
+      s_run<A, LC, J0>(c, pre);   // one barrier per executed op (fp_run_barriers)
+      FP_STAMP(2);
+      if (CONST_OPS && t == 0) {  // the embedding is final once the program has run: keep it for the rest of the fragment
+        for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) ztile[k] = lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)];
+        c.skip_ops = CONST_OPS;
+      }
+      s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs
+      if (has_value && c.want_value && tid < rows) value[(size_t)t * n + env0 + tid] = lds[v_base + tid * v_ld];
+      PolSample st = smp;
+      st.counter = smp.counter + (unsigned int)t;
+      pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
+                  logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
+      __syncthreads();   // O: the action is in LDS; the next pass starts at once (its inputs were ready long ago)
+      FP_STAMP(3);
+    }
+    return;
+  }
+
+  // ====================================================================== waves 4..7: the env roles, lanes 0..15
+  const int role = wave - POL_WAVES;
+  const bool col = lane < POL_TILE;          // this lane has a column of the hand-over arrays
+  const bool live = lane < rows;
+  const int i = env0 + lane;
+  const int il = live ? i : a.n - 1;         // lanes past the batch work on a copy of the last env (no stores)
+  EnvRegs e;
+  load_env_planes<true, false, false>(a.g, a.npad, il, e);
+  float ref0[4] = {a.ref[0], a.ref[1], a.ref[2], a.ref[3]};
+  if (a.ref_mode == QD_REF_STATIC && a.per_env_ref) {
+    const float4 r = a.g[G_REF * a.npad + il];
+    ref0[0] = r.x; ref0[1] = r.y; ref0[2] = r.z; ref0[3] = r.w;
+  }
+  // what the network executes per step, passed in the same order: G0 G1 | layer barriers | (log-prob reduction) | O
+  const int nb_first = fp_run_barriers<A>(want_value, 0u), nb_later = fp_run_barriers<A>(want_value, CONST_OPS);
+  const int extra = logp ? 1 : 0;
+#define FP_PASS_REST(nb)                                      \
+  do {                                                        \
+    for (int k_ = 3; k_ < (nb) + extra; k_++) coop_barrier(); \
+    coop_barrier(); /* O */                                   \
+  } while (0)
+
+  if (role == 0) {
+    // ================================================================ wave A: factorisation, solve, integration, resets; the filter
+    if (col) {
+      fp_put_state(L.st, lane, e.s);
+      L.info[lane] = make_uint4(0u, e.episode, (uint32_t)e.num_steps, 0u);
+    }
+    coop_barrier();   // P
+    Factor<double> f;
+    Rhs<double> r;
+    M3<float> R;
+    V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
+    for (int t = 0; t < T; t++) {
+      coop_barrier();   // G0
+      coop_barrier();   // G1
+      FP_STAMP(16);
+      // ---------------------------------------------------------- stage 1
+      if (col) {
+        const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
+        f = mass_factor<RC_PRE>(e.M, tg, a.h);
+        rc_ref(a, i, e.num_steps, ref0, e.ref);
+        rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc);
+        rc_pin(f.s11, f.s12, f.s22); rc_pin(f.imt, f.m2, f.hb);
+        if constexpr (RC_PRE) {
+          rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
+          rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
+        } else {
+          rc_pin(f.S); rc_pin(f.p1); rc_pin(f.p2); rc_pin(f.d0, f.d1, f.d2); rc_pin(f.l10, f.l20, f.l21);
+        }
+      }
+      FP_STAMP(17);
+      coop_barrier();   // layer barrier 1
+      // ---------------------------------------------------------- stage 2
+      if (col) {
+        {
+          Applied<float> ap;
+          {
+            const float4 x0 = L.app[0][lane], x1 = L.app[1][lane], x2 = L.app[2][lane], x3 = L.app[3][lane], x4 = L.app[4][lane];
+            ap.F = mk<float>(x0.x, x0.y, x0.z); ap.t1 = x0.w;
+            ap.Tq = mk<float>(x1.x, x1.y, x1.z); ap.t2 = x1.w;
+            R.m00 = x2.x; R.m01 = x2.y; R.m02 = x2.z; R.m10 = x2.w; R.m11 = x3.x; R.m12 = x3.y; R.m20 = x3.z; R.m21 = x3.w; R.m22 = x4.x;
+          }
+          Inertial<double> in;
+          {
+            const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
+            in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
+          }
+          r = reduce_rhs<RC_PRE>(f, ap, in);
+        }
+        w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
+        Accel<float> im;
+        V3<double> a0im;
+        finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+        im.lin = mul(R, cvt<float>(a0im));
+        integrate_motion<float, true>(e.s, im, a.h);
+        e.flags &= ~FLAG_ACC_STALE;
+        e.num_steps += 1;
+        const int steps_post = e.num_steps;
+        bool tr;
+        {
+          const float dx = e.s.px - e.ref[0], dy = e.s.py - e.ref[1], dz = e.s.pz - e.ref[2];
+          const float dist = qsqrt(dx * dx + dy * dy + dz * dz);
+          tr = spec_term<SPEC>(a) == QD_TERM_SIMPLE ? dist > 0.5f : (!(dist <= a.max_distance) || e.num_steps >= a.max_steps);
+        }
+        const bool rst = a.auto_reset && tr;
+        if (rst) {
+          fp_put_state(L.pre, lane, e.s);
+          State<float> ns;   // the new episode's state; the activations carry over (reset_bookkeeping) and are filtered below
+          sample_episode<true>(a, i, e.episode, ns);
+          ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
+          e.s = ns;
+          reset_bookkeeping(e.s, e.episode, e.num_steps);
+          e.flags |= FLAG_ACC_STALE;
+        }
+        fp_put_state(L.st, lane, e.s);
+        L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
+        trt[lane] = tr ? 1 : 0;   // the next pass's previous-action gather (read after O)
+      }
+      FP_STAMP(18);
+      coop_barrier();   // layer barrier 2
+      coop_barrier();   // layer barrier 3 (wave D's stage)
+      FP_PASS_REST(t == 0 ? nb_first : nb_later);
+      FP_STAMP(19);
+      // ---------------------------------------------------------- the action is known: the part of the Euler step that reads it
+      if (col) {
+        const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
+        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
+        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        L.st[4][lane] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);   // waves B and C read it behind the next two barriers
+      }
+      FP_STAMP(20);
+    }
+    // what a per-step launch leaves in the arena: the state, and the reading of the last step (quirk C-6; stale where that step reset)
+    if (live) {
+      e.acc = rc_sensor(f, r, R, w0);
+      store_env(a, i, e);
+    }
+  } else if (role == 1) {
+    // ================================================================ wave B: thrust + drag on the three bodies
+    coop_barrier();   // P
+    for (int t = 0; t < T; t++) {
+      coop_barrier();   // G0
+      coop_barrier();   // G1
+      if (col) {
+        State<float> s;
+        fp_get_state(L.st, lane, s);
+        const Tether<float> tg = tether_geometry(s.th1, s.th2);
+        const Att<float> at = attitude(s);
+        const Applied<float> ap = applied_wrench(e.M, s, at, tg);
+        L.app[0][lane] = make_float4(ap.F.x, ap.F.y, ap.F.z, ap.t1);
+        L.app[1][lane] = make_float4(ap.Tq.x, ap.Tq.y, ap.Tq.z, ap.t2);
+        L.app[2][lane] = make_float4(at.R.m00, at.R.m01, at.R.m02, at.R.m10);
+        L.app[3][lane] = make_float4(at.R.m11, at.R.m12, at.R.m20, at.R.m21);
+        L.app[4][lane] = make_float4(at.R.m22, 0.f, 0.f, 0.f);
+      }
+      coop_barrier();   // layer barrier 1
+      coop_barrier();   // layer barrier 2
+      coop_barrier();   // layer barrier 3
+      FP_PASS_REST(t == 0 ? nb_first : nb_later);
+    }
+  } else if (role == 2) {
+    // ================================================================ wave C: gravity + velocity products
+    coop_barrier();   // P
+    for (int t = 0; t < T; t++) {
+      coop_barrier();   // G0
+      coop_barrier();   // G1
+      if (col) {
+        State<float> s;
+        fp_get_state(L.st, lane, s);
+        const Tether<float> tg = tether_geometry(s.th1, s.th2);
+        V3<float> gt, w;
+        gravity_body(s, &gt, &w);
+        const Inertial<double> in = inertial_wrench(e.M, s, gt, w, tg);
+        L.ine[0][lane] = make_double2(in.F.x, in.F.y);
+        L.ine[1][lane] = make_double2(in.F.z, in.Tq.x);
+        L.ine[2][lane] = make_double2(in.Tq.y, in.Tq.z);
+        L.ine[3][lane] = make_double2(in.t1, in.t2);
+      }
+      coop_barrier();   // layer barrier 1
+      coop_barrier();   // layer barrier 2
+      coop_barrier();   // layer barrier 3
+      FP_PASS_REST(t == 0 ? nb_first : nb_later);
+    }
+  } else {
+    // ================================================================ wave D: the observation row (stage 3); reward and flags once the action is known
+    coop_barrier();   // P
+    for (int t = 0; t < T; t++) {
+      coop_barrier();   // G0
+      coop_barrier();   // G1
+      coop_barrier();   // layer barrier 1
+      coop_barrier();   // layer barrier 2: s_{t+1}, the flags and (truncated lanes) the state before the reset are published
+      FP_STAMP(40);
+      float sv[33];
+      M3<float> Rq;
+      float ref_t[4] = {0.f, 0.f, 0.f, 0.f};
+      uint4 info = make_uint4(0u, 0u, 0u, 0u);
+      bool rst = false;
+      if (col) {
+        EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
+        fp_get_state(L.st, lane, ed.s);
+        info = L.info[lane];
+        rst = (info.x & 2u) != 0u;
+        rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
+        ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
+        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
+        drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
+        if (live) write_obs_row<true, SPEC>(a, ed, sv, &Rq, otile + lane * D);
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
+      FP_STAMP(41);
+      coop_barrier();   // layer barrier 3
+      FP_PASS_REST(t == 0 ? nb_first : nb_later);
+      FP_STAMP(42);
+      if (col) {
+        const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
+        const float act4[4] = {u.x, u.y, u.z, u.w};
+        const bool simple = spec_term<SPEC>(a) == QD_TERM_SIMPLE;
+        float rw;
+        if (simple) {   // SimpleDrone.step's reward on this model (env_step: 0.1 - |pos - ref|)
+          const float dx = sv[0] - ref_t[0], dy = sv[1] - ref_t[1], dz = sv[2] - ref_t[2];
+          rw = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
+        } else {
+          rw = qd::reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
+        }
+        if (__any(rst ? 1 : 0)) {   // the reward of a truncated lane is of the state BEFORE its reset
+          State<float> pst;
+          fp_get_state(L.pre, lane, pst);
+          float sv2[33];
+          M3<float> Rq2;
+          drone_state<float, true>(pst, mk<float>(0.f, 0.f, 0.f), ref_t, e.par, sv2, &Rq2);
+          float rw2;
+          if (simple) {
+            const float dx = sv2[0] - ref_t[0], dy = sv2[1] - ref_t[1], dz = sv2[2] - ref_t[2];
+            rw2 = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
+          } else {
+            rw2 = qd::reward<float>(spec_reward<SPEC>(a), sv2, act4, (int)info.z, ref_t, a.max_distance, &Rq2);
+          }
+          if (rst) rw = rw2;
+        }
+        if (live) {
+          __builtin_nontemporal_store(rw, reward + (size_t)t * n + i);
+          __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc + (size_t)t * n + i);
+        }
+      }
+      FP_STAMP(43);
+    }
+  }
+#undef FP_PASS_REST
+}
+
+// ---- host ----
+hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa, size_t lds_bytes, int T, const PolSample& smp,
+                                     const float* obs0, const float* prev0, float* obs, float* actions, float* reward, uint8_t* trunc,
+                                     float* logp, float* logits, float* value, hipStream_t stream) {
+  KArgs kk = k;
+  kk.use_pool = 0;
+  kk.main_blocks = 0;
+  const dim3 grid((k.n + POL_TILE - 1) / POL_TILE), block(FP_THREADS);
+  (void)hipGetLastError();
+#define FP_LAUNCH(ARCH)                                                                                                                  \
+  hipLaunchKernelGGL((k_rollout_fused_pipe<SPEC_RMA, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
+                     reward, trunc, logp, logits, value)
+  switch (arch) {
+    case 1: FP_LAUNCH(ArchRmaFull); break;
+    case 2: FP_LAUNCH(ArchRmaModel); break;
+    case 7: FP_LAUNCH(ArchCustomMlp); break;
+    case 9: FP_LAUNCH(ArchRmaSmaller); break;
+    default: return hipErrorNotSupported;
+  }
+#undef FP_LAUNCH
+  return hipGetLastError();
+}
+
+}  // namespace qd
+
+#ifdef QD_STAMPS
+extern "C" int qd_debug_read_fpstamps(unsigned long long* out_host) {
+  return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd::qd_fpstamps), sizeof(qd::qd_fpstamps));
+}
+#endif
