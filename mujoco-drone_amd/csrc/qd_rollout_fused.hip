@@ -34,6 +34,7 @@ struct FpLds {                 // the env waves' hand-over: one column per env o
   float4 st[6][POL_TILE];      // A -> B, C, D: the state the next step starts from (rc_put_state's planes)
   float4 pre[6][POL_TILE];     // A -> D: the state before the reset of a truncated lane (its reward is of this state)
   uint4 info[POL_TILE];        // A -> D: (bit 0 truncated | bit 1 reset), episode counter, num_steps after the step, -
+  int tag;                     // A -> D: t + 1 once st / pre / info of step t are published (wave D polls it: no barrier of its own to wait at)
 };
 
 __device__ __forceinline__ void fp_put_state(float4 (*st)[POL_TILE], int lane, const State<float>& s) {
@@ -81,6 +82,40 @@ constexpr int fp_min_barriers() {   // actor only, parameter encoder skipped: th
   return nb;
 }
 
+// The next pass's gathered inputs, prepared by wave D while the network is still busy: buffers 0 and 1 as the leading COPY_OBS ops
+// fill them (zero elsewhere), in a staging copy the network moves in with one float4 per thread -- the gather itself (index
+// arithmetic with divisions by the slice widths, two rounds of LDS latency) took 1.0 of the pass's 8.6 us at its head.
+template <class A, int I, int LC>
+__device__ __forceinline__ void fp_stage_obs(const float* otile, float* stage, int rows, int lane) {
+  if constexpr (I < LC) {
+    constexpr SOp op = A::prog.op[I];
+    static_assert(op.kind == POL_COPY_OBS || op.kind == POL_COPY_PREV, "feed-forward networks: the leading ops gather from the row and the previous action");
+    if constexpr (op.kind == POL_COPY_OBS) {
+      constexpr int n = op.in_dim, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off, od = A::prog.obs_dim;
+      for (int k = lane; k < POL_TILE * n; k += 64) {
+        const int r = k / n, c = k - r * n;
+        stage[out_base + r * ld + c] = r < rows ? otile[r * od + op.in_off + c] : 0.f;
+      }
+    }
+    fp_stage_obs<A, I + 1, LC>(otile, stage, rows, lane);
+  }
+}
+// the leading COPY_PREV ops (s_copy_load / s_copy_store on the LDS tiles): zero where the last step truncated the env
+template <class A, int I, int LC>
+__device__ __forceinline__ void fp_gather_prev(float* lds, const float* atile, const uint8_t* trt, int rows, int tid) {
+  if constexpr (I < LC) {
+    constexpr SOp op = A::prog.op[I];
+    if constexpr (op.kind == POL_COPY_PREV) {
+      constexpr int n = op.in_dim, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off, ad = A::prog.act_dim;
+      for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
+        const int r = k / n, c = k - r * n;
+        lds[out_base + r * ld + c] = (r < rows && !trt[r]) ? atile[r * ad + op.in_off + c] : 0.f;
+      }
+    }
+    fp_gather_prev<A, I + 1, LC>(lds, atile, trt, rows, tid);
+  }
+}
+
 #ifdef QD_STAMPS
 // diagnostic build: s_memrealtime (10 ns) stamps of the last step, [0..15] network (thread 0), [16 + 8 role + k] the env waves
 __device__ unsigned long long qd_fpstamps[64];
@@ -102,6 +137,9 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
   static_assert(fp_min_barriers<A>() >= 3, "three layer barriers per step carry the three env stages");
   extern __shared__ float lds[];
   __shared__ FpLds L;
+  constexpr int IN_FLOATS_ = POL_TILE * (sp_ld(A::prog, 0) + sp_ld(A::prog, 1));
+  static_assert(sp_base(A::prog, 0) == 0 && sp_base(A::prog, 1) == POL_TILE * sp_ld(A::prog, 0) && IN_FLOATS_ % 4 == 0, "buffers 0 and 1 open the activation area");
+  __shared__ __attribute__((aligned(16))) float stage[IN_FLOATS_];   // wave D -> network: the gathered inputs of the next pass
   constexpr int ACT = sp_act_floats(A::prog), S4 = sp_small_floats(A::prog) / 4, SIT = (S4 + POL_THREADS - 1) / POL_THREADS;
   constexpr int D = A::prog.obs_dim, AD = A::prog.act_dim, LC = sp_leading_copies(A::prog), J0 = sp_next_dense(A::prog, 0);
   constexpr int IN_FLOATS = POL_TILE * (sp_ld(A::prog, 0) + sp_ld(A::prog, 1));  // buffers 0 and 1 take the gathered inputs
@@ -156,13 +194,24 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     constexpr bool has_value = A::prog.value_buf >= 0;
     for (int t = 0; t < T; t++) {
       FP_STAMP(0);
-      SLead<A, 0, LC> lead;
-      lead.load(c);
-      for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;  // the input buffers also held last step's outputs
-      __syncthreads();   // G0
-      lead.store(c);
-      if (CONST_OPS && t > 0)  // z of step 0 back into its slice of the input buffer (cleared above); the encoder ops are skipped
-        for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
+      if (t == 0) {   // the first pass gathers from the tiles the prologue filled (k_rollout_fused's two phases)
+        SLead<A, 0, LC> lead;
+        lead.load(c);
+        for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;
+        FP_STAMP(4);
+        __syncthreads();   // G0
+        FP_STAMP(5);
+        lead.store(c);
+      } else {        // later passes: wave D staged buffers 0 and 1 during the last pass (the input buffers also held its outputs)
+        for (int k = tid; k < IN_FLOATS / 4; k += POL_THREADS) reinterpret_cast<float4*>(lds)[k] = reinterpret_cast<const float4*>(stage)[k];
+        FP_STAMP(4);
+        __syncthreads();   // G0
+        FP_STAMP(5);
+        fp_gather_prev<A, 0, LC>(lds, atile, trt, rows, tid);
+        if (CONST_OPS)  // z of step 0 back into its slice of the input buffer; the encoder ops are skipped
+          for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
+      }
+      FP_STAMP(6);
       __syncthreads();   // G1
       FP_STAMP(1);
       s_run<A, LC, J0>(c, pre);   // one barrier per executed op (fp_run_barriers)
@@ -173,10 +222,12 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       }
       s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs
       if (has_value && c.want_value && tid < rows) value[(size_t)t * n + env0 + tid] = lds[v_base + tid * v_ld];
+      FP_STAMP(7);
       PolSample st = smp;
       st.counter = smp.counter + (unsigned int)t;
       pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
                   logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
+      FP_STAMP(8);
       __syncthreads();   // O: the action is in LDS; the next pass starts at once (its inputs were ready long ago)
       FP_STAMP(3);
     }
@@ -211,13 +262,26 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       fp_put_state(L.st, lane, e.s);
       L.info[lane] = make_uint4(0u, e.episode, (uint32_t)e.num_steps, 0u);
     }
+    if (lane == 0) L.tag = 0;
     coop_barrier();   // P
     Factor<double> f;
     Rhs<double> r;
     M3<float> R;
     V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
+    // the part of the Euler step that reads the action: the activation filter.  It runs a pass LATE, between the next pass's two
+    // gather barriers -- waves B and C read the activations behind the second one -- so that the network never waits for it.
+    auto filter = [&]() {
+      if (col) {
+        const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
+        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
+        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        L.st[4][lane] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
+      }
+    };
     for (int t = 0; t < T; t++) {
       coop_barrier();   // G0
+      if (t > 0) filter();   // with the action of step t - 1 (the network rewrites the tile at the end of this pass)
       coop_barrier();   // G1
       FP_STAMP(16);
       // ---------------------------------------------------------- stage 1
@@ -282,21 +346,16 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
         trt[lane] = tr ? 1 : 0;   // the next pass's previous-action gather (read after O)
       }
+      // published: wave D starts on the row at once (value, then tag -- a wave's LDS operations execute in order)
+      asm volatile("" ::: "memory");
+      if (lane == 0) *(volatile int*)&L.tag = t + 1;
       FP_STAMP(18);
       coop_barrier();   // layer barrier 2
       coop_barrier();   // layer barrier 3 (wave D's stage)
       FP_PASS_REST(t == 0 ? nb_first : nb_later);
       FP_STAMP(19);
-      // ---------------------------------------------------------- the action is known: the part of the Euler step that reads it
-      if (col) {
-        const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
-        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
-        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
-        L.st[4][lane] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);   // waves B and C read it behind the next two barriers
-      }
-      FP_STAMP(20);
     }
+    filter();   // the last step's
     // what a per-step launch leaves in the arena: the state, and the reading of the last step (quirk C-6; stale where that step reset)
     if (live) {
       e.acc = rc_sensor(f, r, R, w0);
@@ -349,37 +408,19 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       FP_PASS_REST(t == 0 ? nb_first : nb_later);
     }
   } else {
-    // ================================================================ wave D: the observation row (stage 3); reward and flags once the action is known
+    // ================================================================ wave D: the observation row; reward and flags a pass late
     coop_barrier();   // P
-    for (int t = 0; t < T; t++) {
-      coop_barrier();   // G0
-      coop_barrier();   // G1
-      coop_barrier();   // layer barrier 1
-      coop_barrier();   // layer barrier 2: s_{t+1}, the flags and (truncated lanes) the state before the reset are published
-      FP_STAMP(40);
-      float sv[33];
-      M3<float> Rq;
-      float ref_t[4] = {0.f, 0.f, 0.f, 0.f};
-      uint4 info = make_uint4(0u, 0u, 0u, 0u);
-      bool rst = false;
-      if (col) {
-        EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
-        fp_get_state(L.st, lane, ed.s);
-        info = L.info[lane];
-        rst = (info.x & 2u) != 0u;
-        rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
-        ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
-        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
-        drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
-        if (live) write_obs_row<true, SPEC>(a, ed, sv, &Rq, otile + lane * D);
-      }
-      __builtin_amdgcn_wave_barrier();
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
-      FP_STAMP(41);
-      coop_barrier();   // layer barrier 3
-      FP_PASS_REST(t == 0 ? nb_first : nb_later);
-      FP_STAMP(42);
+    float sv[33];
+    M3<float> Rq;
+    float ref_t[4] = {0.f, 0.f, 0.f, 0.f};
+    uint4 info = make_uint4(0u, 0u, 0u, 0u);
+    bool rst = false;
+#pragma unroll
+    for (int k = 0; k < 33; k++) sv[k] = 0.f;
+    Rq.m00 = Rq.m01 = Rq.m02 = Rq.m10 = Rq.m11 = Rq.m12 = Rq.m20 = Rq.m21 = Rq.m22 = 0.f;
+    // reward and flags of step `ts` from what the row's construction left in registers and the action in the tile.  Like the filter
+    // it runs behind the next pass's gather barriers (the state before a truncated lane's reset is overwritten after layer barrier 1).
+    auto settle = [&](int ts) {
       if (col) {
         const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
         const float act4[4] = {u.x, u.y, u.z, u.w};
@@ -407,12 +448,52 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
           if (rst) rw = rw2;
         }
         if (live) {
-          __builtin_nontemporal_store(rw, reward + (size_t)t * n + i);
-          __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc + (size_t)t * n + i);
+          __builtin_nontemporal_store(rw, reward + (size_t)ts * n + i);
+          __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc + (size_t)ts * n + i);
         }
       }
+    };
+    for (int t = 0; t < T; t++) {
+      coop_barrier();   // G0
+      coop_barrier();   // G1
+      FP_STAMP(42);
+      if (t > 0) settle(t - 1);
       FP_STAMP(43);
+      coop_barrier();   // layer barrier 1
+      // s_{t+1}, the flags and (truncated lanes) the state before the reset: as soon as wave A has published them, not a barrier later
+      // (wave A never waits for this wave, so the poll ends; it is bounded all the same)
+      for (int spins = 0; spins < (1 << 20); spins++) {
+        if (*(volatile int*)&L.tag == t + 1) break;
+        __builtin_amdgcn_s_sleep(2);
+      }
+      asm volatile("" ::: "memory");
+      FP_STAMP(40);
+      if (col) {
+        EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
+        fp_get_state(L.st, lane, ed.s);
+        info = L.info[lane];
+        rst = (info.x & 2u) != 0u;
+        rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
+        ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
+        if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
+        drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
+        if (live) write_obs_row<true, SPEC>(a, ed, sv, &Rq, otile + lane * D);
+      }
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
+      FP_STAMP(41);
+      coop_barrier();   // layer barrier 2
+      coop_barrier();   // layer barrier 3
+      // the next pass's inputs (everything but the previous action): the network is two layers from its outputs, this wave idle
+      for (int k = lane; k < IN_FLOATS / 4; k += 64) reinterpret_cast<float4*>(stage)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+      __builtin_amdgcn_wave_barrier();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      fp_stage_obs<A, 0, LC>(otile, stage, rows, lane);
+      FP_STAMP(44);
+      FP_PASS_REST(t == 0 ? nb_first : nb_later);
     }
+    settle(T - 1);
   }
 #undef FP_PASS_REST
 }

@@ -31,9 +31,10 @@ if hasattr(lib, "qd_debug_read_fpstamps") and os.environ.get("QD_FUSED_PIPE", "1
     b = st[0]
     us = lambda k: (st[k] - b) / 100.0
     print("   last step, us since the pass started (thread 0 / lane 0 of each env wave):")
-    print("   network : inputs gathered %.2f, layers done %.2f, action in LDS %.2f" % (us(1), us(2), us(3)))
-    print("   wave A  : stage 1 %.2f .. %.2f, stage 2 done %.2f, after O %.2f, filter done %.2f" % (us(16), us(17), us(18), us(19), us(20)))
-    print("   wave D  : stage 3 %.2f .. %.2f, after O %.2f, reward done %.2f" % (us(40), us(41), us(42), us(43)))
+    print("   network : gather loads issued %.2f, past G0 %.2f, stored %.2f, past G1 %.2f, layers done %.2f, outputs start %.2f, done %.2f, past O %.2f"
+          % (us(4), us(5), us(6), us(1), us(2), us(7), us(8), us(3)))
+    print("   wave A  : stage 1 %.2f .. %.2f, stage 2 done %.2f, after O %.2f" % (us(16), us(17), us(18), us(19)))
+    print("   wave D  : reward of the step before %.2f .. %.2f, row %.2f .. %.2f" % (us(42), us(43), us(40), us(41)))
 elif hasattr(lib, "qd_debug_read_pstamps"):
     buf = (C.c_ulonglong * 64)()
     assert lib.qd_debug_read_pstamps(buf) == 0
