@@ -64,7 +64,8 @@ struct PolArgs {
 typedef float pol_f32x4 __attribute__((ext_vector_type(4)));
 
 #if defined(QD_STAMPS) && !defined(QD_POL_SECOND_UNIT)
-// diagnostic build only: s_memrealtime (100 MHz) stamps of wave 0 of workgroup 0 after every op's barrier
+// diagnostic build only: s_memrealtime (100 MHz) stamps of wave 0 of workgroup 0 after every op's barrier.  Not in the pipelined
+// rollout's unit: under its 256-register cap the per-op stamps change the allocation enough to slow the network by a third.
 __device__ unsigned long long qd_pstamps[64];
 #define POL_STAMP(k)                                                                                                  \
   do {                                                                                                                \

@@ -79,14 +79,15 @@ __device__ __forceinline__ float pol_normal(const PolSample& s, uint32_t env, ui
 
 __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, int AD, int env0, int n_envs, int tid, float* scratch,
                                             const PolSample& smp, float* __restrict__ actions, float* __restrict__ logp,
-                                            float* __restrict__ logits, float* act_lds = nullptr, int dist = POL_DIST_BETA) {
+                                            float* __restrict__ logits, float* act_lds = nullptr, int dist = POL_DIST_BETA,
+                                            float* prev_dst = nullptr, int prev_ld = 0, const uint8_t* prev_trunc = nullptr, int prev_rows = 0) {
   if (logits)
     for (int k = tid; k < POL_TILE * NL; k += POL_THREADS) {
       const int r = k / NL, c = k - r * NL;
       if (env0 + r < n_envs) logits[(size_t)(env0 + r) * NL + c] = lgt[r * ldl + c];
     }
   const int H = NL >> 1;
-  if (actions || logp || act_lds) {
+  if (actions || logp || act_lds || prev_dst) {
     for (int k = tid; k < POL_TILE * H; k += POL_THREADS) {
       const int r = k / H, c = k - r * H;
       float x, lp = 0.f;
@@ -116,6 +117,8 @@ __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, i
       }
       if (actions && env0 + r < n_envs) actions[(size_t)(env0 + r) * AD + c] = x;
       if (act_lds) act_lds[r * AD + c] = x;  // fused rollouts: the env step of the same workgroup consumes it
+      // pipelined rollouts: also as the next pass's previous-action input (the COPY_PREV gather: zero behind a truncation)
+      if (prev_dst) prev_dst[r * prev_ld + c] = (r < prev_rows && !prev_trunc[r]) ? x : 0.f;
       if (logp && H <= POL_SCRATCH / POL_TILE) scratch[r * H + c] = lp;
     }
   }

@@ -100,22 +100,13 @@ __device__ __forceinline__ void fp_stage_obs(const float* otile, float* stage, i
     fp_stage_obs<A, I + 1, LC>(otile, stage, rows, lane);
   }
 }
-// the leading COPY_PREV ops (s_copy_load / s_copy_store on the LDS tiles): zero where the last step truncated the env
-template <class A, int I, int LC>
-__device__ __forceinline__ void fp_gather_prev(float* lds, const float* atile, const uint8_t* trt, int rows, int tid) {
-  if constexpr (I < LC) {
-    constexpr SOp op = A::prog.op[I];
-    if constexpr (op.kind == POL_COPY_PREV) {
-      constexpr int n = op.in_dim, ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off, ad = A::prog.act_dim;
-      for (int k = tid; k < POL_TILE * n; k += POL_THREADS) {
-        const int r = k / n, c = k - r * n;
-        lds[out_base + r * ld + c] = (r < rows && !trt[r]) ? atile[r * ad + op.in_off + c] : 0.f;
-      }
-    }
-    fp_gather_prev<A, I + 1, LC>(lds, atile, trt, rows, tid);
-  }
+template <class A>
+constexpr int fp_prev_op() {   // the leading COPY_PREV op (-1: none, -2: more than one)
+  int at = -1;
+  for (int I = 0; I < sp_leading_copies(A::prog); I++)
+    if (A::prog.op[I].kind == POL_COPY_PREV) at = at == -1 ? I : -2;
+  return at;
 }
-
 #ifdef QD_STAMPS
 // diagnostic build: s_memrealtime (10 ns) stamps of the last step, [0..15] network (thread 0), [16 + 8 role + k] the env waves
 __device__ unsigned long long qd_fpstamps[64];
@@ -150,6 +141,10 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
   uint8_t* trt = reinterpret_cast<uint8_t*>(atile + POL_TILE * AD);  // [16] truncated flags of the last step
   constexpr unsigned CONST_OPS = fused_const_ops<A>;
   constexpr int ZD = CONST_OPS ? A::prog.aux_dim : 0;
+  constexpr int PV = fp_prev_op<A>();
+  static_assert(PV >= 0 && A::prog.op[PV >= 0 ? PV : 0].in_off == 0 && A::prog.op[PV >= 0 ? PV : 0].in_dim == A::prog.act_dim,
+                "one leading gather takes the whole previous action");
+  constexpr int prev_base = sp_base(A::prog, A::prog.op[PV].out_buf) + A::prog.op[PV].out_off, prev_ld = sp_ld(A::prog, A::prog.op[PV].out_buf);
   float* ztile = atile + POL_TILE * AD + 16;   // [16][aux_dim] the parameter embedding of the first step
   constexpr int z_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, z_ld = sp_ld(A::prog, A::prog.aux_buf);
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = tid & 63;
@@ -202,13 +197,14 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         __syncthreads();   // G0
         FP_STAMP(5);
         lead.store(c);
-      } else {        // later passes: wave D staged buffers 0 and 1 during the last pass (the input buffers also held its outputs)
+      } else {
+        // later passes: wave D staged buffers 0 and 1 during the last pass (the input buffers also held its outputs), the output
+        // stage added the previous action; only the pass after the first still fetches the parameter embedding itself
         for (int k = tid; k < IN_FLOATS / 4; k += POL_THREADS) reinterpret_cast<float4*>(lds)[k] = reinterpret_cast<const float4*>(stage)[k];
         FP_STAMP(4);
         __syncthreads();   // G0
         FP_STAMP(5);
-        fp_gather_prev<A, 0, LC>(lds, atile, trt, rows, tid);
-        if (CONST_OPS)  // z of step 0 back into its slice of the input buffer; the encoder ops are skipped
+        if (CONST_OPS && t == 1)
           for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
       }
       FP_STAMP(6);
@@ -226,7 +222,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       PolSample st = smp;
       st.counter = smp.counter + (unsigned int)t;
       pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
-                  logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
+                  logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist,
+                  stage + prev_base, prev_ld, trt, rows);
       FP_STAMP(8);
       __syncthreads();   // O: the action is in LDS; the next pass starts at once (its inputs were ready long ago)
       FP_STAMP(3);
@@ -490,6 +487,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       fp_stage_obs<A, 0, LC>(otile, stage, rows, lane);
+      if (CONST_OPS && t >= 1)   // the parameter embedding of the first pass (the network stashed it behind that pass's layers)
+        for (int k = lane; k < POL_TILE * ZD; k += 64) stage[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
       FP_STAMP(44);
       FP_PASS_REST(t == 0 ? nb_first : nb_later);
     }
