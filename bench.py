@@ -638,7 +638,10 @@ def main():
                     t1 = time.perf_counter()
                     pol.rollout(e3._dev, 1024, o3)
                     torch.cuda.synchronize()
-                    extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / (time.perf_counter() - t1)
+                    dt = time.perf_counter() - t1
+                    extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / dt
+                    extras["policy_closed_loop_us_per_step"] = dt / 1024 * 1e6
+                    extras["policy_closed_loop_kernel"] = "qd::k_rollout_fused_pipe (env step beside the forward pass)" if n <= 16384 else "two launches per step"
                     extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
                 for other in ("config2", "config3", "config5"):
                     if other == args.config:

@@ -6,7 +6,8 @@ usage: python profiles/summarize.py <round-tag> <stats_dir> [--kernel substring]
   --grid    : keep only dispatches of this grid size (a run holds launches of other env counts too)
   --cut     : a persistent kernel's duration (and every counter) scales with its step count, which the trace does not carry.  The
               longest dispatches of a bench.py run are its 1024-step fragments; with x = value / (max value / 1024) as the step
-              estimate of a dispatch, only those with x within [0.97 * 1024, ...] (cut = 1024) or [0.8 cut, 1.25 cut + 8] (shorter
+              estimate of a dispatch (the typical longest launch, not one slow outlier, as the reference), only those within 3 % of that
+              reference (cut = 1024; --tol) or with x in [0.8 cut, 1.25 cut + 8] (shorter
               runs: the +8 is the fixed cost of a launch in units of steps) are summarised; recorded as steps_per_launch
   stats_dir : output of  rocprofv3 --kernel-trace --stats --output-format csv -d <dir> -- python bench.py ...
   pmc dirs  : outputs of rocprofv3 --kernel-trace --pmc <counters> --output-format csv -d <dir> -- python bench.py ...
@@ -45,11 +46,23 @@ def select(rows, grid, cut):
 
 
 LONGEST = 1024     # --longest: the step count of the longest launches of the profiled command (bench.py --fragment)
+TOL = 0.97         # --tol: a launch belongs to the longest cluster when it lasts at least this share of the longest one
+
+
+def long_centre(v):
+    """the typical value of the LONGEST-step launches: the centre of the most populated +-3 % window among the values of at least
+    half the maximum (the maximum itself may be one slow outlier: a first launch, a clock ramp)"""
+    cand = v[v >= 0.5 * v.max()]
+    counts = [(np.abs(cand - d) <= 0.03 * d).sum() for d in cand]
+    return float(cand[int(np.argmax(counts))])
 
 
 def cut_mask(v, cut):
-    x = v / (v.max() / float(LONGEST))
-    return x >= 0.97 * LONGEST if cut >= LONGEST else (x >= 0.8 * cut) & (x <= 1.25 * cut + 8)
+    c = long_centre(v)
+    if cut >= LONGEST:
+        return np.abs(v - c) <= (1.0 - TOL) * c
+    x = v / (c / float(LONGEST))
+    return (x >= 0.8 * cut) & (x <= 1.25 * cut + 8)
 
 
 def trace_stats(d, key="k_step", grid=0, cut=0):
@@ -98,6 +111,9 @@ def main():
         if a == "--longest":
             global LONGEST
             LONGEST = int(sys.argv[j + 1])
+        if a == "--tol":
+            global TOL
+            TOL = float(sys.argv[j + 1])
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "mujoco-drone_amd"))
     try:    # the library the profiled command loaded was built from these sources (bench.py checks the hash before quoting a profile)
         import build as _b

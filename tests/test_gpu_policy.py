@@ -234,6 +234,50 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
                 np.testing.assert_allclose(x, y, atol=2e-5)
 
 
+def test_pipelined_rollout_many_workgroups_distance_truncation_moving_reference(PG, monkeypatch):
+    """k_rollout_fused_pipe (env step beside the forward pass) past one workgroup per CU: 4096 + 37 envs = 259 workgroups, the last one
+    ragged; truncation by distance as well as by step count (max_distance 0.35 at state_difficulty 1), a circling waypoint, and the
+    arena left as the per-step path leaves it.  Reference: qd_policy_act + qd_step per step on a twin env fed the same actions."""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward
+    monkeypatch.delenv("QD_POLICY_GENERIC", raising=False)
+    pol = DevicePolicy("RMA_full", weights_of(PG, "rma_full"))
+    assert pol.kernel > 0
+    n, T = 4096 + 37, 14
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward, random_params=True, param_difficulty=1,
+               state_difficulty=1.0, max_steps=11, max_distance=0.35, auto_reset=True,
+               reference_trajectory={"type": "circle", "radius": 0.3, "frequency": 0.5})
+    e1, e2 = LocalFrameRPYParamsEnv(cfg), LocalFrameRPYParamsEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    assert torch.equal(o1, o2)
+    out = pol.rollout(e1._dev, T, o1, want_logits=True)
+    obs, prev, tr = o2, None, None
+    by_distance = 0
+    for t in range(T):
+        a, lg = pol.forward(obs, prev, tr, want_logits=True)
+        np.testing.assert_allclose(out["logits"][t].cpu().numpy(), lg.cpu().numpy(), atol=2e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(out["actions"][t].cpu().numpy(), a.cpu().numpy(), atol=2e-5)
+        ob, rw, trn = e2.vector_step_tensor(out["actions"][t])
+        obs, prev, tr = ob.clone(), out["actions"][t], trn.clone()
+        np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), atol=2e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=2e-5)
+        assert torch.equal(out["truncated"][t], tr)
+        if t < 10:
+            by_distance += int(tr.sum())
+    assert by_distance > n // 20                      # the distance rule fired well before max_steps did
+    for x, y in zip(e1._dev.get_state(), e2._dev.get_state()):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), atol=2e-5)
+    # the next per-step launch continues from what the fragment left (stale sensor flags, episode counters, activations)
+    act = torch.rand((n, 4), device="cuda")
+    oa, ra, ta = e1.vector_step_tensor(act)
+    ob, rb, tb = e2.vector_step_tensor(act)
+    np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), atol=2e-5)
+    assert torch.equal(ta, tb)
+
+
 HIST = {"RMA_full_adapt": ("rma_adapt", 22, lambda P, w, oh, ah: P.rma_full_adapt(w, oh, ah)[:2]),
         "CNNestimator_estimate": ("cnn_est_hist", 23, lambda P, w, oh, ah: P.cnn_estimator_hist(w, oh, ah)[:2])}
 

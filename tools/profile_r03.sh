@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-3 profile collection on the GPU box (run through gpurun from the repository root); summaries land in gpurun_out/prof_r03/,
 # tools/install_profiles_r03.py copies them into profiles/ and writes profiles/current.json (which bench.py reads, hash-checked).
-# usage: tools/profile_r03.sh <part>   with part = trace | pmc | sq | big | c25
+# usage: tools/profile_r03.sh <part>   with part = trace | pmc | sq | big | c25 | policy
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r03; RAW=/tmp/prof_raw; mkdir -p $OUT $RAW
@@ -57,6 +57,12 @@ big)
     rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $RAW/${1}bw -- python3 bench.py --config $1 $A $B > /dev/null
     python3 profiles/summarize.py r03_pmc_${1}_n1048576 $RAW/${1}bt --kernel "$2" --out $OUT --grid $3 --cut 64 --longest 64 --pmc fetch=$RAW/${1}bf --pmc write=$RAW/${1}bw
   done
+  ;;
+policy)
+  # the closed policy -> env loop (RMA_full actor, 4096 envs, 256-step fragments): k_rollout_fused_pipe, duration and matrix-pipe share
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/pol -- python3 tests/diag_fused_stamps.py 4096 > $OUT/r03_policy_loop_wall.txt
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $RAW/polq -- python3 tests/diag_fused_stamps.py 4096 > /dev/null
+  python3 profiles/summarize.py r03_policy_loop_n4096 $RAW/pol --kernel k_rollout_fused_pipe --out $OUT --grid 131072 --cut 256 --longest 256 --tol 0.85 --pmc sq=$RAW/polq
   ;;
 esac
 ls -la $OUT
