@@ -130,10 +130,11 @@ __device__ __forceinline__ int rc_acc_slot(int kind) {
 // their OCC = 1 instantiation.
 //
 // PID: the action source is the reference's analytic cascade (qd_pid.h; models/Analytic/*.py wired as attitude_test.py:36-47) instead
-// of an action tensor.  The action of step t is a function of s_t; wave C, which reads s_t at the start of every round and has the
-// shortest phase 1, evaluates the controller there (its memory stays in that wave's registers) and publishes the action before
-// barrier 1; wave A applies the activation filter at the start of phase 2, wave D reads it for the reward.  `actions_out` [T,N,4]
-// (nullable) receives the actions.
+// of an action tensor.  The action of step t is a function of s_t, but the step itself does not wait for it: the motors are filters
+// (the thrust of step t comes from the activations a_t; u_t only enters a_{t+1}), so wave B evaluates the controller in phase 2 of
+// round t, beside wave A's solve (its memory stays in wave B's registers), and the filter is applied a round late -- by wave A to
+// the activations it publishes, by wave B to its own copy for the thrust, by wave D for rows that carry the activations -- from the
+// action published in L.act before barrier 2.  `actions_out` [T,N,4] (nullable) receives the actions.
 template <int SPEC, int OCC, bool PID>
 __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
                                                              float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out,
@@ -194,6 +195,15 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
           L.acc[lane] = make_float4(acc_t.x, acc_t.y, acc_t.z, 0.f);
         }
       }
+      // PID: the controller's action of round t - 1 (wave B evaluated it during that round's phase 2, beside this wave's solve).  The
+      // motors are filters: u only enters the NEXT state's activations, so nothing of round t - 1 waited for it; it is applied here,
+      // before this round publishes them (wave B, which needs a_t for the thrust now, applies the same filter to its own copy).
+      if (PID && t >= 1 && t <= T) {
+        const float4 u = L.act[lane];
+        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
+        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+      }
       if (t == rounds) break;
       const float4 action = act_next;
       if (!PID && t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
@@ -239,7 +249,6 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
       if (!half) {
-        if (PID) filter(L.act[lane]);   // wave C evaluated the controller on s_t during phase 1
         Accel<float> im;
         V3<double> a0im;
         finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
@@ -299,12 +308,25 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       store_env(a, i, e);
     }
   } else if (role == 1) {
-    // ================================================================ wave B: thrust + drag on the three bodies
+    // ================================================================ wave B: thrust + drag on the three bodies; the PID cascade
+    // PID instantiations: the controller pair of this lane's env lives in this wave's registers (arena planes C0..C3 between launches).
+    // It is evaluated on s_t in PHASE 2 of round t, which this wave otherwise idles through: the action u_t is not needed before the
+    // activations of s_{t+1} are (see wave A), i.e. by this wave's own thrust at the start of round t + 1.  (Round 3 first had the
+    // cascade in wave C's phase 1, in front of barrier 1: 1.92 us per step against 1.35 with given actions.)
+    PidState<float> pc;
+    pid_reset(pc);
+    if (PID) load_pid(a, il, pc);
+    float4 u_last = make_float4(0.f, 0.f, 0.f, 0.f);
     coop_barrier();   // P
     for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
       State<float> s;
       rc_get_state(L.st, lane, s);
+      if (PID && t >= 1) {   // the published activations are one filter step behind: a_t = filter(a_{t-1}, u_{t-1})
+        float c0 = u_last.x, c1 = u_last.y, c2 = u_last.z, c3 = u_last.w;
+        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+        integrate_act(e.M, s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+      }
       const Tether<float> tg = tether_geometry(s.th1, s.th2);
       const Att<float> at = attitude(s);
       const Applied<float> ap = applied_wrench(e.M, s, at, tg);
@@ -313,13 +335,33 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       L.app[2][lane] = make_float4(at.R.m00, at.R.m01, at.R.m02, at.R.m10);
       L.app[3][lane] = make_float4(at.R.m11, at.R.m12, at.R.m20, at.R.m21);
       L.app[4][lane] = make_float4(at.R.m22, 0.f, 0.f, 0.f);
+      uint4 info = make_uint4(0u, 0u, 0u, 0u);
+      if (PID) info = L.info[lane];   // of s_t (wave A rewrites it in phase 2)
       RC_STAMP(1);
       coop_barrier();   // 1
       RC_STAMP(2);
+      if (PID && t < T) {
+        // A lane reset in the last step starts with fresh controller objects; the waypoint is that of the episode step s_t is at.
+        const bool rst = (info.x & 2u) != 0u;
+        if (rst) pid_reset(pc);
+        EnvRegs ed;
+        ed.s = s;
+        rc_ref(a, i, rst ? 0 : (int)info.z, ref0, ed.ref);
+#pragma unroll
+        for (int k = 0; k < 6; k++) ed.par[k] = e.par[k];
+        u_last = pid_env_action(pc, ed);
+        L.act[lane] = u_last;
+        if (actions_out && live) reinterpret_cast<float4*>(actions_out)[(size_t)t * n + i] = u_last;
+      }
+      RC_STAMP(3);
       coop_barrier();   // 2
       RC_STAMP(4);
     }
     if (sens) coop_barrier();   // E
+    if (PID && live) {   // the controller memory back to the arena (fresh objects where the last step reset the lane)
+      if ((L.info[lane].x & 2u) != 0u) pid_reset(pc);
+      store_pid(a, i, pc);
+    }
   } else if (role == 2) {
     // ================================================================ wave C: gravity + velocity products; the reset sampler
     const bool pool = a.use_pool != 0 && a.auto_reset != 0;
@@ -346,9 +388,6 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
     jns.px = jns.py = jns.pz = jns.qw = jns.qx = jns.qy = jns.qz = jns.th1 = jns.th2 = 0.f;
     jns.vx = jns.vy = jns.vz = jns.wx = jns.wy = jns.wz = jns.thd1 = jns.thd2 = jns.a0 = jns.a1 = jns.a2 = jns.a3 = 0.f;
     int jphase = 0;
-    PidState<float> pc;   // PID instantiations: the controller pair of this lane's env (arena planes C0..C3 between launches)
-    pid_reset(pc);
-    if (PID) load_pid(a, il, pc);
     for (int t = 0; t < rounds; t++) {
       RC_STAMP(0);
       if (jphase == JOB_DONE) {   // commit: wave A is in its phase 1 and does not read the pool
@@ -360,24 +399,6 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       const uint4 info = L.info[lane];
       const uint32_t episode = info.y;
       const float4 tag0 = L.nxt[0][4][lane], tag1 = L.nxt[1][4][lane];
-      if (PID && t < T) {
-        // The controller on s_t, for step t.  This wave's phase 1 is the shortest of the three, but the ~250 instructions of the
-        // cascade still make it the last one at barrier 1 (2.07 us per step against 1.48 with given actions; in wave D, which has
-        // the row to build, 2.18).  Tried and not kept: the controller in wave B's idle phase 2 with an in-phase hand-over to wave A
-        // (value, then a round tag wave A polls before it applies the filter) -- wave A then waits for the cascade inside its own
-        // phase 2 instead of at the barrier: 2.25 us.  A lane reset in the last step starts with fresh controller objects; the
-        // waypoint is that of the episode step s_t is at.
-        const bool rst = (info.x & 2u) != 0u;
-        if (rst) pid_reset(pc);
-        EnvRegs ed;
-        ed.s = s;
-        rc_ref(a, i, rst ? 0 : (int)info.z, ref0, ed.ref);
-#pragma unroll
-        for (int k = 0; k < 6; k++) ed.par[k] = e.par[k];
-        const float4 act_now = pid_env_action(pc, ed);
-        L.act[lane] = act_now;
-        if (actions_out && live) reinterpret_cast<float4*>(actions_out)[(size_t)t * n + i] = act_now;
-      }
       const Tether<float> tg = tether_geometry(s.th1, s.th2);
       V3<float> gt, w;
       gravity_body(s, &gt, &w);
@@ -416,10 +437,6 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       RC_STAMP(4);
     }
     if (sens) coop_barrier();   // E
-    if (PID && live) {   // the controller memory back to the arena (fresh objects where the last step reset the lane)
-      if ((L.info[lane].x & 2u) != 0u) pid_reset(pc);
-      store_pid(a, i, pc);
-    }
     // hand the pool back to the arena as the per-step kernels expect it: the entry of every env's current counter and of the
     // one after it, complete (what the chunked job had not finished is sampled here, once per fragment); entries are "state
     // only" (POOL_STATE): a per-step kernel of a sensor-reading configuration adds the second stage itself
@@ -461,9 +478,16 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       bool rst = false;
       const bool row_now = t >= 1 && t <= T;   // the row of step t - 1 is the observation of s_t
       float* tile_now = L.tile[(t - 1) & 1];
+      // PID: the action of step t - 1 (wave B published it in that round's phase 2)
+      if (PID && row_now) act_prev = L.act[lane];
       if (row_now) {
         EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
         rc_get_state(L.st, lane, ed.s);
+        if (PID) {   // the published activations are one filter step behind (wave A applies u_{t-1} at the top of this round)
+          float c0 = act_prev.x, c1 = act_prev.y, c2 = act_prev.z, c3 = act_prev.w;
+          if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+          integrate_act(e.M, ed.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        }
         info = L.info[lane];
         rst = (info.x & 2u) != 0u;
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
@@ -522,8 +546,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       }
       acc_prev = acc_new;
       rst_prev = rst;
-      if (PID) { if (t < T) act_prev = L.act[lane]; }   // wave C's controller output of this round (published before barrier 1)
-      else if (t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
+      if (!PID && t < T) act_prev = actions4[(size_t)t * n + il];   // for iteration t + 1: in flight across the barrier
       RC_STAMP(3);
       if (t < rounds) coop_barrier();   // 2
       RC_STAMP(4);

@@ -530,3 +530,35 @@ def test_generic_and_pid_instantiations_at_two_workgroups_per_cu(qd):
     assert float(d[..., 12:15].max()) <= 5e-3
     d[..., 12:15] = 0
     assert float(d.max()) <= 3e-4, float(d.max())
+
+
+def test_pid_fragment_rows_that_carry_the_activations_and_fragment_cuts(qd):
+    """The PID-driven persistent kernel applies the controller's action a round late (the motors are filters: the step does not wait
+    for it).  Raw observation rows (BaseDroneEnv._get_obs) carry the activations, so they show whether every wave sees the same
+    filtered values: against T x (qd_pid_action, qd_step), with resets every 7 steps, and the same rollout cut into three
+    fragments (the last filter step is applied when a fragment ends) bit for bit."""
+    L, n, T = qd._lib, 1000, 36
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs="BaseDroneEnv", reward="default_reward_fcn", start=1, random_params=1,
+                                             auto_reset=1, max_steps=7, seed=31))
+    a, b, c = mk(), mk(), mk()
+    for e in (a, b, c):
+        e.reset(); e.pid_reset()
+    assert a.fragment_kernel_name() == "qd::k_rollout_coop<4,1>"
+    O, R, Tr, A = a.rollout_pid(T, want_actions=True)
+    worst = 0.0
+    for t in range(T):
+        act = b.pid_action()
+        o, r, tr = b.step(act)
+        b.pid_reset(tr)          # a new episode starts with fresh controller objects (the rollout kernels do this in the step)
+        assert torch.equal(Tr[t], tr), t
+        np.testing.assert_allclose(A[t].cpu().numpy(), act.cpu().numpy(), atol=2e-4, err_msg="t=%d" % t)
+        d = _heading_safe_absdiff(O[t], o)
+        worst = max(worst, float(d.max()))
+        assert float(d.max()) <= 3e-3 and float((R[t] - r).abs().max()) <= 2e-3, (t, float(d.max()))
+    assert int(Tr.sum()) == (T // 7) * n
+    parts = [c.rollout_pid(k, want_actions=True) for k in (5, 19, 12)]
+    for j, name in enumerate(("obs", "reward", "truncated", "actions")):
+        got = torch.cat([p[j] for p in parts])
+        assert torch.equal(got, (O, R, Tr, A)[j]), name
+    for x, y in zip(a.get_state(), c.get_state()):
+        assert torch.equal(x, y)
