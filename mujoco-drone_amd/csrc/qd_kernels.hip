@@ -568,11 +568,11 @@ __global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs 
   constexpr int ZD = CONST_OPS ? A::prog.aux_dim : 0;
   float* ztile = atile + POL_TILE * AD + 16;
   constexpr int z_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, z_ld = sp_ld(A::prog, A::prog.aux_buf);
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = tid & 63;
   const int env0 = blockIdx.x * POL_TILE, rows = min(POL_TILE, a.n - env0), n = a.n;
   SCtx c;
   c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
-  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
+  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
   c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
   c.n_envs = rows; c.env0 = 0; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings

@@ -276,7 +276,8 @@ template <> inline constexpr unsigned fused_const_ops<ArchRmaSmaller> = (1u << 3
 struct SCtx {
   float* lds;
   const float* small;      // LDS mirror of the small region
-  const float4* weights;   // packed weights + lane
+  const float4* weights;   // packed weights (workgroup-uniform: with a uniform wave index the tile pointers stay in SGPRs)
+  int lane;                // every load adds the lane: [tile][kblock][lane][4]
   const float* obs;
   const float* prev_actions;
   const uint8_t* prev_truncated;
@@ -315,7 +316,7 @@ __device__ __forceinline__ void s_prefetch(const SCtx& c, SPre<A, I>& pre) {
     for (int u = 0; u < SDense<A, I>::U0; u++) {
       const float4* src = s_tile_ptr<A, I>(c, u);
 #pragma unroll
-      for (int kb = 0; kb < SDense<A, I>::PB; kb++) pre.w[kb][u] = src[kb * 64];
+      for (int kb = 0; kb < SDense<A, I>::PB; kb++) pre.w[kb][u] = src[kb * 64 + c.lane];
     }
   }
 }
@@ -353,7 +354,7 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
       float4 w[UMAX];
 #pragma unroll
       for (int u = 0; u < UMAX; u++)
-        if (u < U) w[u] = (g0 == 0 && kb < PB) ? pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0] : wp[u][kb * 64];
+        if (u < U) w[u] = (g0 == 0 && kb < PB) ? pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0] : wp[u][kb * 64 + c.lane];
 #pragma unroll
       for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[u].x, acc[u], 0, 0, 0);
 #pragma unroll
@@ -561,10 +562,10 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   constexpr int ACT = sp_act_floats(A::prog);
   SCtx c;
   c.lds = lds; c.small = lds + ACT;
-  c.tid = threadIdx.x; c.wave = c.tid >> 6;
+  c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = c.tid & 63;
   c.li = lane & 15; c.lg = lane >> 4;
-  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
+  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter; c.skip_ops = 0u;

@@ -155,7 +155,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     // ==================================================================== waves 0..3: the network (k_rollout_fused's forward pass)
     SCtx c;
     c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
-    c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off) + lane;
+    c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
     c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
     c.n_envs = rows; c.env0 = 0; c.want_value = want_value;
     c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
@@ -217,11 +217,15 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         c.skip_ops = CONST_OPS;
       }
       s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs
-      if (has_value && c.want_value && tid < rows) value[(size_t)t * n + env0 + tid] = lds[v_base + tid * v_ld];
+      // (the output addresses are functions of the thread index alone; left to itself the compiler computes them once, before the
+      // loop, and with 256 registers keeps them in scratch: an opaque copy of the index makes it recompute them, a few instructions)
+      int tid_o = tid;
+      asm volatile("" : "+v"(tid_o));
+      if (has_value && c.want_value && tid_o < rows) value[(size_t)t * n + env0 + tid_o] = lds[v_base + tid_o * v_ld];
       FP_STAMP(7);
       PolSample st = smp;
       st.counter = smp.counter + (unsigned int)t;
-      pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
+      pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid_o, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
                   logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist,
                   stage + prev_base, prev_ld, trt, rows);
       FP_STAMP(8);
