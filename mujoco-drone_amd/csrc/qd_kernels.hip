@@ -528,126 +528,6 @@ __global__ __launch_bounds__(64) void k_rollout_pid(KArgs a, int T, float* __res
   }
 }
 
-// the env phase of the fused loop as a real call: its ~250 registers (float64 core) are allocated apart from the policy code's
-template <bool LOAD, int SPEC>
-__device__ __attribute__((noinline)) void fused_env_phase(const KArgs& a, int i, const float* action4, float* obs_row, float* reward_out,
-                                                          uint8_t* trunc_out, uint8_t* trunc_lds) {
-  EnvRegs e;
-  load_env<LOAD, false>(a, i, e);
-  const float4 action = *reinterpret_cast<const float4*>(action4);
-  float r;
-  uint8_t tr;
-  env_step<LOAD, SPEC>(a, i, e, action, obs_row, &r, &tr);
-  store_env(a, i, e);
-  *reward_out = r;
-  *trunc_out = tr;
-  *trunc_lds = tr;
-}
-
-// ---- fused closed loop: policy forward + env step for T steps in ONE launch ----
-// A workgroup owns 16 envs for the whole fragment: the four waves run the specialised policy network on the matrix
-// cores (qd_policy_static.h), then lanes 0..15 of wave 0 advance their envs and hand the new observation rows to the
-// next forward pass through LDS.  Against the two-launch loop this removes the inter-kernel gaps and the per-launch
-// prologue of the policy kernel, and the next step's first weights are already in flight during the env step.
-template <bool LOAD, int SPEC, class A>
-__global__ __launch_bounds__(POL_THREADS) void k_rollout_fused(KArgs a, PolArgs p, int T, PolSample smp, const float* __restrict__ obs0,
-                                                               const float* __restrict__ prev0, float* __restrict__ obs,
-                                                               float* __restrict__ actions, float* __restrict__ reward,
-                                                               uint8_t* __restrict__ trunc, float* __restrict__ logp,
-                                                               float* __restrict__ logits, float* __restrict__ value) {
-  extern __shared__ float lds[];
-  constexpr int ACT = sp_act_floats(A::prog), S4 = sp_small_floats(A::prog) / 4, SIT = (S4 + POL_THREADS - 1) / POL_THREADS;
-  constexpr int D = A::prog.obs_dim, AD = A::prog.act_dim, LC = sp_leading_copies(A::prog), J0 = sp_next_dense(A::prog, 0);
-  constexpr int IN_FLOATS = POL_TILE * (sp_ld(A::prog, 0) + sp_ld(A::prog, 1));  // buffers 0 and 1 take the gathered inputs
-  float* small = lds + ACT;
-  float* otile = small + S4 * 4;           // [16][D] observation rows: obs0, then what the env step of the last iteration wrote
-  float* atile = otile + POL_TILE * D;     // [16][4] actions of the last iteration (previous action of the next)
-  uint8_t* trt = reinterpret_cast<uint8_t*>(atile + POL_TILE * AD);  // [16] truncated flags of the last iteration
-  // [16][aux_dim] the parameter embedding z of the first step (networks with fused_const_ops), behind the 64 bytes reserved for trt
-  constexpr unsigned CONST_OPS = fused_const_ops<A>;
-  constexpr int ZD = CONST_OPS ? A::prog.aux_dim : 0;
-  float* ztile = atile + POL_TILE * AD + 16;
-  constexpr int z_base = sp_base(A::prog, A::prog.aux_buf) + A::prog.aux_off, z_ld = sp_ld(A::prog, A::prog.aux_buf);
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), lane = tid & 63;
-  const int env0 = blockIdx.x * POL_TILE, rows = min(POL_TILE, a.n - env0), n = a.n;
-  SCtx c;
-  c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
-  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
-  c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
-  c.n_envs = rows; c.env0 = 0; c.want_value = value != nullptr;
-  c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
-  c.skip_ops = 0u;
-  SPre<A, J0> pre;
-  s_prefetch<A, J0>(c, pre);
-  {  // prologue: parameters mirror, first observation / previous action, cleared activations
-    const float4* src = reinterpret_cast<const float4*>(p.packed + p.prog_ints);
-    float4 sm[SIT];
-#pragma unroll
-    for (int it = 0; it < SIT; it++) {
-      const int k = tid + it * POL_THREADS;
-      sm[it] = k < S4 ? src[k] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-    for (int k = tid; k < POL_TILE * D; k += POL_THREADS) otile[k] = k < rows * D ? obs0[(size_t)env0 * D + k] : 0.f;
-    for (int k = tid; k < POL_TILE * AD; k += POL_THREADS) atile[k] = (prev0 && k < rows * AD) ? prev0[(size_t)env0 * AD + k] : 0.f;
-    if (tid < POL_TILE) trt[tid] = 0;
-    for (int k = tid; k < ACT; k += POL_THREADS) lds[k] = 0.f;
-    float4* dst = reinterpret_cast<float4*>(small);
-#pragma unroll
-    for (int it = 0; it < SIT; it++) {
-      const int k = tid + it * POL_THREADS;
-      if (k < S4) dst[k] = sm[it];
-    }
-  }
-  const bool envlane = wave == 0 && lane < rows;
-  const int i = env0 + lane;
-  __syncthreads();
-  constexpr int ldl = sp_ld(A::prog, A::prog.logits_buf), NL = A::prog.n_logits;
-  constexpr int lg_base = sp_base(A::prog, A::prog.logits_buf) + A::prog.logits_off;
-  constexpr int VB = A::prog.value_buf < 0 ? 0 : A::prog.value_buf;
-  constexpr int v_base = sp_base(A::prog, VB) + A::prog.value_off, v_ld = sp_ld(A::prog, VB);
-  constexpr bool has_value = A::prog.value_buf >= 0;
-  for (int t = 0; t < T; t++) {
-    // ---- policy forward on the tiles ----
-    POL_STAMP(40);
-    SLead<A, 0, LC> lead;
-    lead.load(c);
-    for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;  // the input buffers also held last step's outputs
-    __syncthreads();
-    lead.store(c);
-    if (CONST_OPS && t > 0)  // z of step 0 back into its slice of the input buffer (cleared above); the encoder ops are skipped
-      for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
-    __syncthreads();
-    POL_STAMP(41);
-    s_run<A, LC, J0>(c, pre);
-    POL_STAMP(42);
-    if (CONST_OPS && t == 0) {  // the embedding is final once the program has run: keep it for the rest of the fragment
-      for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) ztile[k] = lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)];
-      c.skip_ops = CONST_OPS;
-    }
-    s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs and the env step
-    if (has_value && c.want_value && tid < rows) value[(size_t)t * n + env0 + tid] = lds[v_base + tid * v_ld];
-    PolSample st = smp;
-    st.counter = smp.counter + (unsigned int)t;
-    pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
-                logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist);
-    __syncthreads();
-    POL_STAMP(43);
-    // ---- env step: wave 0, one env per lane ----
-    if (wave == 0) {
-      if (envlane) {
-        // the env state goes through the arena every step (it stays in this CU's L2 slice): holding it in registers across
-        // the policy phase as k_rollout does would add ~70 live registers to the MFMA code
-        fused_env_phase<LOAD, SPEC>(a, i, atile + lane * 4, otile + lane * D, reward + (size_t)t * n + i, trunc + (size_t)t * n + i, trt + lane);
-      }
-      POL_STAMP(44);
-      __builtin_amdgcn_wave_barrier();
-      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
-    }
-    __syncthreads();
-    POL_STAMP(45);
-  }
-}
-
 // _get_obs() of the current state for every env (also used after reset / regen)
 template <bool LOAD, int BLOCK>
 __global__ __launch_bounds__(BLOCK) void k_observe(KArgs a, float* __restrict__ obs) {

@@ -266,7 +266,7 @@ struct ArchDsnLstm {  // DSN_LSTM_model (mujoco_drone_amd/policy.py; table print
 
 // Ops whose result depends on the drone parameters only (the parameter encoder of the RMA networks, writing the auxiliary slice z):
 // within one fused rollout the parameters of an env do not change (in-kernel resets keep them; regeneration is a host call
-// between fragments), so k_rollout_fused runs them on the first step only and keeps z in LDS.
+// between fragments), so the fused rollout (qd_rollout_fused.hip) runs them on the first step only and keeps z in LDS.
 template <class A> inline constexpr unsigned fused_const_ops = 0u;
 template <> inline constexpr unsigned fused_const_ops<ArchRmaFull> = (1u << 3) | (1u << 4);
 template <> inline constexpr unsigned fused_const_ops<ArchRmaModel> = (1u << 3) | (1u << 4);

@@ -10,7 +10,7 @@
 // roles of k_rollout_coop (A factorisation / solve / integration / resets, B applied wrench, C inertial wrench, D observation
 // row), 16 lanes each, and have o_{t+1} in LDS long before the network has u_t.  When it has, wave A applies the filter, wave D
 // evaluates the reward, and the next forward pass starts at once: a step costs the forward pass, not forward pass + env step
-// (k_rollout_fused, one wave of 16 lanes after the network: 11.8 us per step at 4096 envs, 3.6 of them the env phase).
+// (round 2's k_rollout_fused, one wave of 16 lanes after the network: 11.8 us per step at 4096 envs, 3.6 of them the env phase).
 //
 // gfx950 has ONE barrier per workgroup, so the env waves pass exactly the barriers the network executes: two for the input
 // gathers, one per executed layer, one behind the outputs.  The three env stages sit in front of the first three layer barriers
@@ -34,6 +34,7 @@ struct FpLds {                 // the env waves' hand-over: one column per env o
   float4 st[6][POL_TILE];      // A -> B, C, D: the state the next step starts from (rc_put_state's planes)
   float4 pre[6][POL_TILE];     // A -> D: the state before the reset of a truncated lane (its reward is of this state)
   uint4 info[POL_TILE];        // A -> D: (bit 0 truncated | bit 1 reset), episode counter, num_steps after the step, -
+  float4 acc[POL_TILE];        // A -> D: the accelerometer reading in the row of this step (sensor-carrying rows; not for reset lanes)
   int tag;                     // A -> D: t + 1 once st / pre / info of step t are published (wave D polls it: no barrier of its own to wait at)
 };
 
@@ -100,6 +101,23 @@ __device__ __forceinline__ void fp_stage_obs(const float* otile, float* stage, i
     fp_stage_obs<A, I + 1, LC>(otile, stage, rows, lane);
   }
 }
+// the leading COPY_OBS destinations of NV consecutive row entries (what a row carries of the action: known a pass late)
+template <class A, int I, int LC, int NV>
+__device__ __forceinline__ void fp_patch_obs(float* lds, int r, int col0, const float (&w)[NV]) {
+  if constexpr (I < LC) {
+    constexpr SOp op = A::prog.op[I];
+    if constexpr (op.kind == POL_COPY_OBS) {
+      constexpr int ld = sp_ld(A::prog, op.out_buf), out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+#pragma unroll
+      for (int j = 0; j < NV; j++) {
+        const int c = col0 + j;
+        if (c >= op.in_off && c < op.in_off + op.in_dim) lds[out_base + r * ld + (c - op.in_off)] = w[j];
+      }
+    }
+    fp_patch_obs<A, I + 1, LC, NV>(lds, r, col0, w);
+  }
+}
+
 template <class A>
 constexpr int fp_prev_op() {   // the leading COPY_PREV op (-1: none, -2: more than one)
   int at = -1;
@@ -124,7 +142,15 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
                                                                    float* __restrict__ actions, float* __restrict__ reward,
                                                                    uint8_t* __restrict__ trunc, float* __restrict__ logp,
                                                                    float* __restrict__ logits, float* __restrict__ value) {
-  static_assert(SPEC == SPEC_RMA, "the observation row must not read the accelerometer or the activations");
+  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM, "the observation row must not read the activations");
+  // SPEC_LSTM rows (LocalFrameFullStateEnv, 23 values) carry two things more.  The accelerometer: the reading mj_step computed in
+  // the step, at the state it STARTED from (quirk C-6) -- the explicit solve of the same pass, no action in it; only a lane that was
+  // reset carries mj_forward's reading at the NEW state with the activations that survived the reset, i.e. the filtered ones, and
+  // that reading is affine in them (sensor_affine: wave A prepares the constant and the four columns with the new state).  And the
+  // four activations themselves.  Both are known when wave A applies the filter, a pass late: it writes them into the network's
+  // input buffers (the gather has run, the first layer has not) and into the entries of the global row that wave D left out.
+  constexpr bool sens = SPEC == SPEC_LSTM;
+  constexpr int acc_at = 12, act_at = 15;   // rc_acc_slot(OBS_FULLSTATE); the activations follow the reading (qd_obsrew.h)
   static_assert(fp_min_barriers<A>() >= 3, "three layer barriers per step carry the three env stages");
   extern __shared__ float lds[];
   __shared__ FpLds L;
@@ -152,7 +178,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
   const bool want_value = value != nullptr;
 
   if (wave < POL_WAVES) {
-    // ==================================================================== waves 0..3: the network (k_rollout_fused's forward pass)
+    // ==================================================================== waves 0..3: the network
     SCtx c;
     c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
     c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
@@ -189,7 +215,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     constexpr bool has_value = A::prog.value_buf >= 0;
     for (int t = 0; t < T; t++) {
       FP_STAMP(0);
-      if (t == 0) {   // the first pass gathers from the tiles the prologue filled (k_rollout_fused's two phases)
+      if (t == 0) {   // the first pass gathers from the tiles the prologue filled (two phases: loads, barrier, stores)
         SLead<A, 0, LC> lead;
         lead.load(c);
         for (int k = tid; k < IN_FLOATS; k += POL_THREADS) lds[k] = 0.f;
@@ -271,18 +297,34 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
     // the part of the Euler step that reads the action: the activation filter.  It runs a pass LATE, between the next pass's two
     // gather barriers -- waves B and C read the activations behind the second one -- so that the network never waits for it.
-    auto filter = [&]() {
+    V3<float> sc0 = mk<float>(0.f, 0.f, 0.f), scol[4] = {sc0, sc0, sc0, sc0}, acc_last = sc0;   // sens: a reset lane's affine form, the last reading
+    bool pend = false;
+    auto filter = [&](int ts) {   // ts: the step whose action this is
       if (col) {
         const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
         float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
         if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
         integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
         L.st[4][lane] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
+        if (sens) {   // what the row of step ts carries of the action
+          float* row = obs + ((size_t)ts * n + i) * D;
+          const float av[4] = {e.s.a0, e.s.a1, e.s.a2, e.s.a3};
+          fp_patch_obs<A, 0, LC, 4>(lds, lane, act_at, av);   // between the gather barriers: the stage copy is in, the first layer not started
+          if (live) { row[act_at] = av[0]; row[act_at + 1] = av[1]; row[act_at + 2] = av[2]; row[act_at + 3] = av[3]; }
+          if (pend) {   // the reset lane's reading at its new state, with the activations it now has
+            const float rd[3] = {sc0.x + scol[0].x * e.s.a0 + scol[1].x * e.s.a1 + scol[2].x * e.s.a2 + scol[3].x * e.s.a3,
+                                 sc0.y + scol[0].y * e.s.a0 + scol[1].y * e.s.a1 + scol[2].y * e.s.a2 + scol[3].y * e.s.a3,
+                                 sc0.z + scol[0].z * e.s.a0 + scol[1].z * e.s.a1 + scol[2].z * e.s.a2 + scol[3].z * e.s.a3};
+            acc_last = mk<float>(rd[0], rd[1], rd[2]);
+            fp_patch_obs<A, 0, LC, 3>(lds, lane, acc_at, rd);
+            if (live) { row[acc_at] = rd[0]; row[acc_at + 1] = rd[1]; row[acc_at + 2] = rd[2]; }
+          }
+        }
       }
     };
     for (int t = 0; t < T; t++) {
       coop_barrier();   // G0
-      if (t > 0) filter();   // with the action of step t - 1 (the network rewrites the tile at the end of this pass)
+      if (t > 0) filter(t - 1);   // with the action of step t - 1 (the network rewrites the tile at the end of this pass)
       coop_barrier();   // G1
       FP_STAMP(16);
       // ---------------------------------------------------------- stage 1
@@ -319,6 +361,11 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
           r = reduce_rhs<RC_PRE>(f, ap, in);
         }
         w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
+        if (sens) {   // the reading of this step (the ONLY place it is evaluated: the arena gets the same bits)
+          acc_last = rc_sensor(f, r, R, w0);
+          L.acc[lane] = make_float4(acc_last.x, acc_last.y, acc_last.z, 0.f);
+        }
+        pend = false;
         Accel<float> im;
         V3<double> a0im;
         finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
@@ -341,7 +388,12 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
           ns.a0 = e.s.a0; ns.a1 = e.s.a1; ns.a2 = e.s.a2; ns.a3 = e.s.a3;
           e.s = ns;
           reset_bookkeeping(e.s, e.episode, e.num_steps);
-          e.flags |= FLAG_ACC_STALE;
+          if (sens) {
+            sensor_affine<float>(e.M, e.s, a.h, &sc0, scol);
+            pend = true;
+          } else {
+            e.flags |= FLAG_ACC_STALE;
+          }
         }
         fp_put_state(L.st, lane, e.s);
         L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
@@ -356,10 +408,10 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       FP_PASS_REST(t == 0 ? nb_first : nb_later);
       FP_STAMP(19);
     }
-    filter();   // the last step's
+    filter(T - 1);   // the last step's
     // what a per-step launch leaves in the arena: the state, and the reading of the last step (quirk C-6; stale where that step reset)
     if (live) {
-      e.acc = rc_sensor(f, r, R, w0);
+      e.acc = sens ? acc_last : rc_sensor(f, r, R, w0);
       store_env(a, i, e);
     }
   } else if (role == 1) {
@@ -478,15 +530,27 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         ed.ref[0] = ref_t[0]; ed.ref[1] = ref_t[1]; ed.ref[2] = ref_t[2]; ed.ref[3] = ref_t[3];
         if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
         drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
-        if (live) write_obs_row<true, SPEC>(a, ed, sv, &Rq, otile + lane * D);
+        if (live) {
+          float* row = otile + lane * D;
+          write_obs_row<true, SPEC>(a, ed, sv, &Rq, row);
+          if (sens) {   // a reset lane's entries follow a pass later (wave A)
+            const float4 x = L.acc[lane];
+            row[acc_at] = rst ? 0.f : x.x; row[acc_at + 1] = rst ? 0.f : x.y; row[acc_at + 2] = rst ? 0.f : x.z;
+          }
+        }
       }
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      for (int k = lane; k < rows * D; k += 64) __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
+      for (int k = lane; k < rows * D; k += 64) {
+        if (sens) {   // (not the entries wave A writes later: two waves' stores to one address have no order)
+          const int r = k / D, c = k - r * D;
+          if ((c >= act_at && c < act_at + 4) || (c >= acc_at && c < acc_at + 3 && (L.info[r].x & 2u))) continue;
+        }
+        __builtin_nontemporal_store(otile[k], obs + ((size_t)t * n + env0) * D + k);
+      }
       FP_STAMP(41);
       coop_barrier();   // layer barrier 2
-      coop_barrier();   // layer barrier 3
-      // the next pass's inputs (everything but the previous action): the network is two layers from its outputs, this wave idle
+      // the next pass's inputs (everything but the previous action): the network has a layer or two to go, this wave is idle
       for (int k = lane; k < IN_FLOATS / 4; k += 64) reinterpret_cast<float4*>(stage)[k] = make_float4(0.f, 0.f, 0.f, 0.f);
       __builtin_amdgcn_wave_barrier();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -494,6 +558,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       if (CONST_OPS && t >= 1)   // the parameter embedding of the first pass (the network stashed it behind that pass's layers)
         for (int k = lane; k < POL_TILE * ZD; k += 64) stage[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)] = ztile[k];
       FP_STAMP(44);
+      coop_barrier();   // layer barrier 3
       FP_PASS_REST(t == 0 ? nb_first : nb_later);
     }
     settle(T - 1);
@@ -510,14 +575,15 @@ hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa
   kk.main_blocks = 0;
   const dim3 grid((k.n + POL_TILE - 1) / POL_TILE), block(FP_THREADS);
   (void)hipGetLastError();
-#define FP_LAUNCH(ARCH)                                                                                                                  \
-  hipLaunchKernelGGL((k_rollout_fused_pipe<SPEC_RMA, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
+#define FP_LAUNCH(SPECV, ARCH)                                                                                                        \
+  hipLaunchKernelGGL((k_rollout_fused_pipe<SPECV, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
                      reward, trunc, logp, logits, value)
   switch (arch) {
-    case 1: FP_LAUNCH(ArchRmaFull); break;
-    case 2: FP_LAUNCH(ArchRmaModel); break;
-    case 7: FP_LAUNCH(ArchCustomMlp); break;
-    case 9: FP_LAUNCH(ArchRmaSmaller); break;
+    case 1: FP_LAUNCH(SPEC_RMA, ArchRmaFull); break;
+    case 2: FP_LAUNCH(SPEC_RMA, ArchRmaModel); break;
+    case 7: FP_LAUNCH(SPEC_RMA, ArchCustomMlp); break;
+    case 9: FP_LAUNCH(SPEC_RMA, ArchRmaSmaller); break;
+    case 5: FP_LAUNCH(SPEC_LSTM, ArchCnnEst); break;   // train_LSTM.py: the 23-value rows with the accelerometer
     default: return hipErrorNotSupported;
   }
 #undef FP_LAUNCH

@@ -17,3 +17,15 @@ for fam in ("RMA_full", "RMA_model", "RMA_model_smaller", "SimpleMLPmodel", "Cus
         pol.rollout(env._dev, 1024, o)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
     print("%-20s %-10s %.2f us/step (%.3e env-steps/s)" % (fam, mode, dt / 1024 * 1e6, n * 1024 / dt), flush=True)
+# train_LSTM.py's pair: CNNestimator on the config-5 env (23-value rows with the accelerometer: env phase behind the network)
+for n5 in (4096, 8192):
+    env, _ = bench.make_env("config5", n5, 42, "cuda:0")
+    pol = DevicePolicy("CNNestimator", random_weights("CNNestimator", 3), obs_dim=23, num_states=23)
+    o = env.vector_reset_tensor().clone()
+    for _ in range(2):
+        pol.rollout(env._dev, 256, o)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(2):
+        pol.rollout(env._dev, 1024, o)
+    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 2
+    print("%-20s %-10s %.2f us/step (%.3e env-steps/s) at %d envs" % ("CNNestimator", mode, dt / 1024 * 1e6, n5 * 1024 / dt, n5), flush=True)

@@ -198,7 +198,7 @@ def test_policy_exploring_rollout_is_a_sample_batch(PG, kernel):
 
 
 def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
-    """k_rollout_fused (one launch per fragment) against the per-step path driven from Python (qd_policy_act + qd_step),
+    """k_rollout_fused_pipe (one launch per fragment, the env step beside the forward pass) against the per-step path driven from Python (qd_policy_act + qd_step),
     deterministic and exploring, with in-kernel auto-resets (truncation every 9 steps) and a ragged env count"""
     from mujoco_drone_amd.policy import DevicePolicy
     from mujoco_drone_amd.environments.BaseDroneEnv import base_config
@@ -276,6 +276,48 @@ def test_pipelined_rollout_many_workgroups_distance_truncation_moving_reference(
     np.testing.assert_allclose(oa.cpu().numpy(), ob.cpu().numpy(), atol=2e-5)
     np.testing.assert_allclose(ra.cpu().numpy(), rb.cpu().numpy(), atol=2e-5)
     assert torch.equal(ta, tb)
+
+
+def test_pipelined_rollout_config5_full_size(PG, monkeypatch):
+    """BASELINE config 5 (train_LSTM.py: 8192 envs, LocalFrameFullStateEnv rows with the accelerometer AND the activations, circling
+    waypoint) through the pipelined kernel: what a row carries of the action -- the four activations, and a reset lane's reading at
+    its new state -- is written a pass late; 8192 + 5 envs = 513 workgroups, resets every 6 steps."""
+    from mujoco_drone_amd.policy import DevicePolicy
+    from mujoco_drone_amd.environments.BaseDroneEnv import base_config
+    from mujoco_drone_amd.environments.observation_wrappers import LocalFrameFullStateEnv
+    from mujoco_drone_amd.environments.rewards import distance_energy_reward_pendulum_en4
+    monkeypatch.delenv("QD_POLICY_GENERIC", raising=False)
+    pol = DevicePolicy("CNNestimator", weights_of(PG, "cnn_est_ff"), obs_dim=23, num_states=23)
+    assert pol.kernel > 0
+    n, T = 8192 + 5, 15
+    cfg = dict(base_config, num_drones=n, reward_fcn=distance_energy_reward_pendulum_en4, random_params=False, state_difficulty=0.8,
+               max_steps=6, auto_reset=True, reference_trajectory=dict(type="circle", radius=1.0, frequency=0.5))
+    e1, e2 = LocalFrameFullStateEnv(cfg), LocalFrameFullStateEnv(cfg)
+    o1, o2 = e1.vector_reset_tensor().clone(), e2.vector_reset_tensor().clone()
+    out = pol.rollout(e1._dev, T, o1, want_logits=True, want_value=True)
+    obs, prev, tr = o2, None, None
+    for t in range(T):
+        a, lg, v = pol.forward(obs, prev, tr, want_logits=True, want_value=True)
+        np.testing.assert_allclose(out["logits"][t].cpu().numpy(), lg.cpu().numpy(), atol=2e-5, err_msg="t=%d" % t)
+        np.testing.assert_allclose(out["value"][t].cpu().numpy(), v.cpu().numpy(), atol=2e-5)
+        ob, rw, trn = e2.vector_step_tensor(out["actions"][t])
+        obs, prev, tr = ob.clone(), out["actions"][t], trn.clone()
+        d = (out["obs"][t] - obs).abs()
+        assert float(d[:, 12:15].max()) <= 2e-3, (t, float(d[:, 12:15].max()))     # the accelerometer (tens of m/s^2, differences of forces)
+        d[:, 12:15] = 0
+        assert float(d.max()) <= 2e-5, (t, float(d.max()), int(d.argmax()) % 23)
+        np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=5e-5)
+        assert torch.equal(out["truncated"][t], tr)
+    assert int(out["truncated"].sum()) == 2 * n
+    for x, y in zip(e1._dev.get_state(), e2._dev.get_state()):
+        np.testing.assert_allclose(x.cpu().numpy(), y.cpu().numpy(), atol=2e-5)
+    act = torch.rand((n, 4), device="cuda")          # the arena the fragment left: readings, flags, counters
+    oa, ra, ta = e1.vector_step_tensor(act)
+    ob, rb, tb = e2.vector_step_tensor(act)
+    d = (oa - ob).abs()
+    assert float(d[:, 12:15].max()) <= 2e-3
+    d[:, 12:15] = 0
+    assert float(d.max()) <= 2e-5 and float((ra - rb).abs().max()) <= 5e-5 and torch.equal(ta, tb)
 
 
 HIST = {"RMA_full_adapt": ("rma_adapt", 22, lambda P, w, oh, ah: P.rma_full_adapt(w, oh, ah)[:2]),
