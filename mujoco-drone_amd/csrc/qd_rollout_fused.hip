@@ -262,6 +262,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
   }
 
   // ====================================================================== waves 4..7: the env roles, lanes 0..15
+  // (each shares its SIMD with a network wave that mostly waits for 32-cycle MFMAs: the env wave's instructions go first)
+  __builtin_amdgcn_s_setprio(3);
   const int role = wave - POL_WAVES;
   const bool col = lane < POL_TILE;          // this lane has a column of the hand-over arrays
   const bool live = lane < rows;
