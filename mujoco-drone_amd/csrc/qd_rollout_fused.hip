@@ -242,7 +242,6 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         for (int k = tid; k < POL_TILE * ZD; k += POL_THREADS) ztile[k] = lds[z_base + (k / (ZD ? ZD : 1)) * z_ld + k % (ZD ? ZD : 1)];
         c.skip_ops = CONST_OPS;
       }
-      s_prefetch<A, J0>(c, pre);  // the next step's first layer: in flight during the outputs
       // (the output addresses are functions of the thread index alone; left to itself the compiler computes them once, before the
       // loop, and with 256 registers keeps them in scratch: an opaque copy of the index makes it recompute them, a few instructions)
       int tid_o = tid;
@@ -254,6 +253,10 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       pol_outputs(lds + lg_base, ldl, NL, AD, env0, n, tid_o, lds + ACT - POL_SCRATCH, st, actions + (size_t)t * n * AD,
                   logp ? logp + (size_t)t * n : nullptr, logits ? logits + (size_t)t * n * NL : nullptr, atile, p.dist,
                   stage + prev_base, prev_ld, trt, rows);
+      // the next pass's first layer: requested behind the output stage, in flight across the barrier and the gather (requested in
+      // front of it, the 32 destination registers collide with the output stage's temporaries under the 256-register cap and the
+      // compiler waits for the loads right there: s_waitcnt vmcnt(1), 0.3 us)
+      s_prefetch<A, J0>(c, pre);
       FP_STAMP(8);
       __syncthreads();   // O: the action is in LDS; the next pass starts at once (its inputs were ready long ago)
       FP_STAMP(3);
