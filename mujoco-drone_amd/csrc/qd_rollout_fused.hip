@@ -8,13 +8,19 @@
 // the reward (its energy term) and the four activations do.  So while waves 0..3 of a workgroup run the network on observation
 // o_t (k_policy_static's code: float32 MFMA, activations in LDS), waves 4..7 advance the same 16 envs from s_t to s_{t+1} in the
 // roles of k_rollout_coop (A factorisation / solve / integration / resets, B applied wrench, C inertial wrench, D observation
-// row), 16 lanes each, and have o_{t+1} in LDS long before the network has u_t.  When it has, wave A applies the filter, wave D
-// evaluates the reward, and the next forward pass starts at once: a step costs the forward pass, not forward pass + env step
-// (round 2's k_rollout_fused, one wave of 16 lanes after the network: 11.8 us per step at 4096 envs, 3.6 of them the env phase).
+// row), 16 lanes each, and have o_{t+1} in LDS long before the network has u_t.  What does read the action runs a pass LATE, off
+// the critical path: wave A applies the filter between the next pass's two gather barriers (waves B and C read the activations
+// behind the second), wave D evaluates reward and flags behind them.  A step costs the forward pass, not forward pass + env step
+// (round 2's k_rollout_fused, one wave of 16 lanes after the network: 11.8 us per step at 4096 envs, 3.6 of them the env phase;
+// this kernel: 7.9).
 //
-// gfx950 has ONE barrier per workgroup, so the env waves pass exactly the barriers the network executes: two for the input
-// gathers, one per executed layer, one behind the outputs.  The three env stages sit in front of the first three layer barriers
-// (the layers behind them take 1.4 / 2.9 / 1.3 us for RMA_full, the stages 0.7 / 0.6 / 0.5), the rest are passed empty.
+// gfx950 has ONE barrier per workgroup, so the env waves pass exactly the barriers the network executes: two at the input
+// gather, one per executed layer, one behind the outputs.  The env stages sit in front of the first three layer barriers: stage 1
+// (the three role waves) before the first, stage 2 (wave A: solve, integration, termination, reset) before the second, wave D's
+// staging of the next pass's inputs before the third; wave D's row waits for no barrier but polls a tag wave A writes behind the
+// new state.  For RMA_full the layers behind those barriers take 1.4 / 2.9 / 1.3 us, the stages 0.5 / 2.0 / 1.1 + 0.4 (stamps,
+// profiles/r03_policy_loop_timeline.txt).  The env waves run at raised priority (s_setprio 3).
+// The 23-value rows of train_LSTM.py's configuration carry the activations and the accelerometer: see SPEC_LSTM in the kernel.
 // Arithmetic: the role functions of qd_dynamics.h on the same values as k_rollout_coop -- equal to the per-step kernels to
 // rounding (tests/test_gpu_policy.py compares with the two-launch loop).  Resets sample inline (a pure function of seed, env,
 // episode: the same states the pool would serve), inside the longest layer's window.
