@@ -540,8 +540,8 @@ def test_pid_fragment_rows_that_carry_the_activations_and_fragment_cuts(qd):
     L, n, T = qd._lib, 1000, 36
     mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs="BaseDroneEnv", reward="default_reward_fcn", start=1, random_params=1,
                                              auto_reset=1, max_steps=7, seed=31))
-    a, b, c = mk(), mk(), mk()
-    for e in (a, b, c):
+    a, b = mk(), mk()
+    for e in (a, b):
         e.reset(); e.pid_reset()
     assert a.fragment_kernel_name() == "qd::k_rollout_coop<4,1>"
     O, R, Tr, A = a.rollout_pid(T, want_actions=True)
@@ -556,9 +556,12 @@ def test_pid_fragment_rows_that_carry_the_activations_and_fragment_cuts(qd):
         worst = max(worst, float(d.max()))
         assert float(d.max()) <= 3e-3 and float((R[t] - r).abs().max()) <= 2e-3, (t, float(d.max()))
     assert int(Tr.sum()) == (T // 7) * n
-    parts = [c.rollout_pid(k, want_actions=True) for k in (5, 19, 12)]
-    for j, name in enumerate(("obs", "reward", "truncated", "actions")):
-        got = torch.cat([p[j] for p in parts])
-        assert torch.equal(got, (O, R, Tr, A)[j]), name
-    for x, y in zip(a.get_state(), c.get_state()):
-        assert torch.equal(x, y)
+    for cuts in ((5, 19, 12), (7, 14, 1, 14)):          # the second: fragments that END on a reset step (7, 21) and a one-step fragment
+        c = mk()
+        c.reset(); c.pid_reset()
+        parts = [c.rollout_pid(k, want_actions=True) for k in cuts]
+        for j, name in enumerate(("obs", "reward", "truncated", "actions")):
+            got = torch.cat([p[j] for p in parts])
+            assert torch.equal(got, (O, R, Tr, A)[j]), (cuts, name)
+        for x, y in zip(a.get_state(), c.get_state()):
+            assert torch.equal(x, y), cuts
