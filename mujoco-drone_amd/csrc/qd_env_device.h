@@ -615,6 +615,16 @@ __device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRe
 #ifndef RC_PRE
 #define RC_PRE true
 #endif
+// The part of the Euler step that reads the action: the reference's ctrl map (BaseDroneEnv.step: 0.1 + 0.9 u for the training
+// configurations), MuJoCo's clamp to the ctrl range, and the activation filter.  One definition: the persistent kernels apply it in
+// several waves (to the solver's state, to the thrust wave's copy, to rows that carry the activations) and must agree bit for bit.
+template <int SPEC>
+__device__ __forceinline__ void rc_filter(const KArgs& a, const Model<float>& M, State<float>& s, float4 u) {
+  float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
+  if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
+  integrate_act(M, s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+}
+
 // the env's reference at episode step k (static: `base`, fetched once)
 __device__ __forceinline__ void rc_ref(const KArgs& a, int i, int k, const float base[4], float ref[4]) {
   if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, k, ref);

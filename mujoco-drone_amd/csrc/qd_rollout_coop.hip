@@ -199,22 +199,14 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       // motors are filters: u only enters the NEXT state's activations, so nothing of round t - 1 waited for it; it is applied here,
       // before this round publishes them (wave B, which needs a_t for the thrust now, applies the same filter to its own copy).
       if (PID && t >= 1 && t <= T) {
-        const float4 u = L.act[lane];
-        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
-        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        rc_filter<SPEC>(a, e.M, e.s, L.act[lane]);
       }
       if (t == rounds) break;
       const float4 action = act_next;
       if (!PID && t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
       f = mass_factor<RC_PRE>(e.M, tg, a.h);
-      auto filter = [&](float4 u) {   // ctrl map and the activation filter: the part of the Euler step that does not wait for the accelerations
-        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
-        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
-      };
-      if (!PID && !half) filter(action);
+      if (!PID && !half) rc_filter<SPEC>(a, e.M, e.s, action);   // ctrl map and activation filter: the part of the Euler step that does not wait for the accelerations
       rc_ref(a, i, e.num_steps, ref0, e.ref);
       // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
       // arithmetic across freely, and left alone it sinks two thirds of the factorisation into phase 2 -- onto the critical
@@ -323,9 +315,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       State<float> s;
       rc_get_state(L.st, lane, s);
       if (PID && t >= 1) {   // the published activations are one filter step behind: a_t = filter(a_{t-1}, u_{t-1})
-        float c0 = u_last.x, c1 = u_last.y, c2 = u_last.z, c3 = u_last.w;
-        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-        integrate_act(e.M, s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        rc_filter<SPEC>(a, e.M, s, u_last);
       }
       const Tether<float> tg = tether_geometry(s.th1, s.th2);
       const Att<float> at = attitude(s);
@@ -484,9 +474,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
         EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
         rc_get_state(L.st, lane, ed.s);
         if (PID) {   // the published activations are one filter step behind (wave A applies u_{t-1} at the top of this round)
-          float c0 = act_prev.x, c1 = act_prev.y, c2 = act_prev.z, c3 = act_prev.w;
-          if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-          integrate_act(e.M, ed.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+          rc_filter<SPEC>(a, e.M, ed.s, act_prev);
         }
         info = L.info[lane];
         rst = (info.x & 2u) != 0u;

@@ -312,10 +312,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     bool pend = false;
     auto filter = [&](int ts) {   // ts: the step whose action this is
       if (col) {
-        const float4 u = *reinterpret_cast<const float4*>(atile + lane * 4);
-        float c0 = u.x, c1 = u.y, c2 = u.z, c3 = u.w;
-        if (spec_ctrl<SPEC>(a) == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
-        integrate_act(e.M, e.s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
+        rc_filter<SPEC>(a, e.M, e.s, *reinterpret_cast<const float4*>(atile + lane * 4));
         L.st[4][lane] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
         if (sens) {   // what the row of step ts carries of the action
           float* row = obs + ((size_t)ts * n + i) * D;
