@@ -1,6 +1,6 @@
 """Diagnostic (not a test): timeline of the four waves of k_rollout_coop for one step in the middle of a fragment, from a
 -DQD_STAMPS build.
-usage: QD_LIB=tests/_build/libqd_stamps.so python tests/diag_rc_stamps.py [T]
+usage: QD_LIB=tests/_build/libqd_stamps.so python tests/diag_rc_stamps.py [T] [pid]     (pid: the PID cascade as the action source)
 (build: python mujoco-drone_amd/build.py --variant stamps -DQD_STAMPS)"""
 import ctypes as C
 import os
@@ -21,8 +21,14 @@ f.actions.copy_(torch.rand(f.actions.shape, device="cuda"))
 lib = env._dev.lib
 buf = (C.c_ulonglong * (64 * 4 * 16))()
 acc = []
+PID = len(sys.argv) > 2 and sys.argv[2] == "pid"
+if PID:
+    env.pid_reset()
 for rep in range(24):
-    env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
+    if PID:
+        env._dev.rollout_pid(T)
+    else:
+        env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
     torch.cuda.synchronize()
     assert lib.qd_debug_read_rcstamps(buf) == 0
     st = np.array(buf[:], dtype=np.int64).reshape(64, 4, 16)[:, :, :5]
@@ -30,7 +36,7 @@ for rep in range(24):
 acc = np.array(acc).reshape(-1, 4, 5)
 med = np.median(acc, axis=0)
 names = ["step start (after barrier 2)", "phase 1 done", "barrier 1 passed", "phase 2 done", "barrier 2 passed"]
-print("k_rollout_coop, step T/2 of a %d-step fragment, %d envs: median cycles since wave A's step start (waves A / B / C / D)" % (T, N))
+print("k_rollout_coop%s, step T/2 of a %d-step fragment, %d envs: median cycles since wave A's step start (waves A / B / C / D)" % (" (PID cascade in wave B's phase 2)" if PID else "", T, N))
 for k, nm in enumerate(names):
     print("  %-30s %7.0f %7.0f %7.0f %7.0f" % (nm, med[0, k], med[1, k], med[2, k], med[3, k]))
 per = acc[:, 0, 4] - acc[:, 0, 0]
