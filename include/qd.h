@@ -202,8 +202,12 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
  *     qd_set_reference invalidates them. */
 int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream);
 /* Per-env switches of launch variants (measurements and A/B tests; results do not depend on them beyond rounding).
- *   QD_OPT_PERSISTENT_FRAGMENTS  1 (default): qd_step_fragment / qd_rollout may run as one persistent launch; 0: never. */
-enum { QD_OPT_PERSISTENT_FRAGMENTS = 0, QD_OPT_COUNT };
+ *   QD_OPT_PERSISTENT_FRAGMENTS  1 (default): qd_step_fragment / qd_rollout may run as one persistent launch; 0: never.
+ *   QD_OPT_LATENCY_KERNEL        1 (default): persistent fragments of at most 16384 envs (256 workgroups, one per CU) of the
+ *                                training configuration run k_rollout_lat (csrc/qd_rollout_lat.hip), whose four wavefronts split
+ *                                the step for the shortest dependent chain; 0: k_rollout_coop at every size (the variant batches
+ *                                above 16384 envs always run: a comparison across the size switch that must be bit-exact sets 0). */
+enum { QD_OPT_PERSISTENT_FRAGMENTS = 0, QD_OPT_LATENCY_KERNEL = 1, QD_OPT_COUNT };
 int qd_set_option(qd_env* env, int option, int value);
 /* The kernel that a qd_step / a qd_step_fragment of this env launches right now (static strings; the variant selector's own
  * answer, for benchmark lines and profiles: "qd::k_step_coop<1>", "qd::k_rollout_coop<1,2>", ...). */

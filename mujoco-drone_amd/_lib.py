@@ -74,6 +74,7 @@ ACT_NONE, ACT_TANH, ACT_RELU = 0, 1, 2
 POL_VALUE_ONLY = 1
 DIST_BETA, DIST_SQUASHED_GAUSSIAN = 0, 1
 OPT_PERSISTENT_FRAGMENTS = 0
+OPT_LATENCY_KERNEL = 1
 
 # every symbol include/qd.h declares: (restype, argtypes)
 _VP, _I, _I64 = C.c_void_p, C.c_int, C.c_int64

@@ -194,13 +194,14 @@ struct Inertial {
   V3<HP> F, Tq;
   HP t1, t2;
 };
-template <class T>
-QD_HD Inertial<typename HighPrec<T>::type> inertial_wrench(const Model<T>& M, const State<T>& s, V3<T> gt, V3<T> w, const Tether<T>& tg) {
-  using HP = typename HighPrec<T>::type;
+// CORE = false: without the core body's share (its weight and gyroscopic moment), which applied_core_link<true>() then carries in
+// float32 on the applied side -- no precision is lost there that the rotor thrust beside it had kept
+template <class T, class HP, bool CORE = true>
+QD_HD Inertial<HP> inertial_wrench_hp(const Model<T>& M, const State<T>& s, V3<T> gt, V3<T> w, V3<HP> dh, V3<HP> y2h) {
   const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc;
   const HP c0z = M.c0z, azh = Const::anchor_z;
   const HP dI = HP(M.I2a) - It;
-  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt), dh = cvt<HP>(tg.d), y2h = cvt<HP>(tg.y2);
+  const V3<HP> wh = cvt<HP>(w), gth = cvt<HP>(gt);
   const V3<HP> uh = mk<HP>(wh.x * wh.z, wh.y * wh.z, -(wh.x * wh.x + wh.y * wh.y));
   const HP thd1 = s.thd1, thd2 = s.thd2;
   const V3<HP> rho = lc * dh;                                         // anchor -> tether COM
@@ -211,9 +212,6 @@ QD_HD Inertial<typename HighPrec<T>::type> inertial_wrench(const Model<T>& M, co
   const V3<HP> al1 = mk<HP>(HP(0), thd1 * wh.z, -thd1 * wh.y);        // thd1 * (w x xhat)
   const V3<HP> al2 = al1 + thd2 * cross(w1, y2h);
   const V3<HP> ac2 = aa + cross(al2, rho) + dot(w2, rho) * w2 - dot(w2, w2) * rho;
-  const V3<HP> F0 = m0 * (gth + c0z * uh);
-  const V3<HP> N0 = mk<HP>(wh.y * wh.z * (HP(M.I0z) - HP(M.I0y)), wh.z * wh.x * (HP(M.I0x) - HP(M.I0z)),
-                           wh.x * wh.y * (HP(M.I0y) - HP(M.I0x)));
   const V3<HP> F1 = m1 * aa;
   const V3<HP> N1 = i1 * al1;
   const V3<HP> F2 = m2 * ac2;
@@ -222,11 +220,49 @@ QD_HD Inertial<typename HighPrec<T>::type> inertial_wrench(const Model<T>& M, co
   const V3<HP> F12 = F1 + F2;
   const HP bd = Const::damping;
   Inertial<HP> in;
-  in.F = F0 + F12;
-  in.Tq = N0 + mk<HP>(-c0z * F0.y, c0z * F0.x, HP(0)) + N1 + mk<HP>(-azh * F12.y, azh * F12.x, HP(0)) + n2v;
+  if (CORE) {
+    const V3<HP> F0 = m0 * (gth + c0z * uh);
+    const V3<HP> N0 = mk<HP>(wh.y * wh.z * (HP(M.I0z) - HP(M.I0y)), wh.z * wh.x * (HP(M.I0x) - HP(M.I0z)),
+                             wh.x * wh.y * (HP(M.I0y) - HP(M.I0x)));
+    in.F = F0 + F12;
+    in.Tq = N0 + mk<HP>(-c0z * F0.y, c0z * F0.x, HP(0)) + N1 + mk<HP>(-azh * F12.y, azh * F12.x, HP(0)) + n2v;
+  } else {
+    in.F = F12;
+    in.Tq = N1 + mk<HP>(-azh * F12.y, azh * F12.x, HP(0)) + n2v;
+  }
   in.t1 = N1.x + n2v.x + bd * thd1;
   in.t2 = dot(y2h, n2v) + bd * thd2;
   return in;
+}
+template <class T>
+QD_HD Inertial<typename HighPrec<T>::type> inertial_wrench(const Model<T>& M, const State<T>& s, V3<T> gt, V3<T> w, const Tether<T>& tg) {
+  using HP = typename HighPrec<T>::type;
+  return inertial_wrench_hp<T, HP, true>(M, s, gt, w, cvt<HP>(tg.d), cvt<HP>(tg.y2));
+}
+// The hinge angles' sine / cosine pairs in HP with s^2 + c^2 = 1 to HP rounding: one Newton step of the inverse square root about 1
+// (the float32 pair is off the unit circle by ~1e-7).  mass_inverse() uses identities of a UNIT tether direction (d.d = 1, d.y2 = 0);
+// fed with the float32 pair as is, its J and B D^-1 B^T -- two numbers of size m2 lc^2 whose difference is the airframe's inertia --
+// disagree at 1e-7 and the accelerations at 2e-4 (host twin).  The inertial wrench of the same step takes the same pairs, so that the
+// load's weight has exactly no moment about the COM the solve uses.
+template <class HP, class T>
+QD_HD void trig_unit(T sf, T cf, HP* s, HP* c) {
+  const HP s0 = sf, c0 = cf;
+  const HP f = HP(1.5) - HP(0.5) * (s0 * s0 + c0 * c0);
+  *s = s0 * f; *c = c0 * f;
+}
+template <class HP>
+struct TetherHP {
+  HP s1, c1, s2, c2;
+  V3<HP> d, y2;
+};
+template <class HP, class T>
+QD_HD TetherHP<HP> tether_hp(T s1f, T c1f, T s2f, T c2f) {
+  TetherHP<HP> t;
+  trig_unit(s1f, c1f, &t.s1, &t.c1);
+  trig_unit(s2f, c2f, &t.s2, &t.c2);
+  t.d = mk<HP>(-t.s2, t.s1 * t.c2, -t.c1 * t.c2);
+  t.y2 = mk<HP>(HP(0), t.c1, t.s1);
+  return t;
 }
 
 // mass matrix about the system COM (sums of non-negative terms), LDL^T of its 3x3 rotational block, the two hinge
@@ -343,6 +379,197 @@ template <class T>
 QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
   const T sz = T(Const::sense_z);
   return a0e + gt + mk<T>(ang_ex.y * sz, -ang_ex.x * sz, T(0)) + sz * u;
+}
+
+// ---- the same reduced system, arranged for the latency-bound persistent kernel (k_rollout_lat, qd_rollout_lat.hip) ----------
+// mass_factor() above costs ~175 float64 instructions per step, most of them the assembly of the inertia about the system COM
+// from its definition.  Everything in that assembly is a function of the unit tether direction d alone, with coefficients that
+// depend on the env's parameters only: with r2 = lc d + az z (tether COM), S = a d + b z (first moment, a = m2 lc,
+// b = m0 c0z + m1 az + m2 az) and Steiner's theorem taken about the ORIGIN and shifted to the COM once,
+//     J  = diag(Kx, Ky, Kz) - 2 k3 dz 1 + k2 d d^T + k3 (d z^T + z d^T)          (Jzz = Kz + k2 dz^2: the dz terms cancel)
+//     B1 = (b1c - k3 dz) x + k2 dx d              B2 = (d2c - k3 dz) y2 + k3 s1 d
+//     D1 = base + dI s2^2 + mul2 c2^2             D2 = d2c            rc = kl d + rz0 z       (m2/mt) p1,2 = kl (x, y2) x d
+// (k2 = dI - mu lc^2, k3 = -m2 lc (az - b/mt), mul2 = mu lc^2, mu = m2 (mt - m2) / mt: the reduced mass of the tether against
+// the rest).  LatConsts holds those coefficients, computed once per launch in float64.
+// The elimination order is turned round as well: the hinge block is DIAGONAL, so the hinges go first (two reciprocals, one of
+// them a per-env constant) and the 3x3 that is left, J' = J - e1 B1 B1^T - e2 B2 B2^T, is inverted by its adjugate (one more
+// reciprocal) instead of an LDL^T with three; the result is kept as the symmetric inverse of the whole 5x5 rotational + hinge
+// system, so that the solve -- the serial half of a step -- is 5 dot products of 5 terms:
+//     [alpha]   [ C    -U1   -U2 ] [fwr]
+//     [thdd1] = [-U1^T  s11   s12 ] [g1 ]        C = J'^-1, U_i = C (e_i B_i), s_ij = delta_ij e_i + (e_i B_i) . U_j
+//     [thdd2]   [-U2^T  s12   s22 ] [g2 ]
+// Only the damping-implicit system (e_i = 1 / (D_i + h b), what the integration uses) is formed: the accelerometer reading needs
+// the explicit one and stays with mass_factor() (sensor-carrying observation variants do not run this path).
+// Same equations as forward(): tests/test_host_twin.py::test_latency_pieces_equal_the_monolithic_forward, 1e-11 in float64.
+template <class HP>
+struct LatConsts {
+  HP Kx, Ky, Kz, k2, k3, b1c, d2c, base, dI, mul2, kl, rz0, imt, hb, e2;
+};
+template <class T>
+QD_HD LatConsts<typename HighPrec<T>::type> lat_consts(const Model<T>& M, T h) {
+  using HP = typename HighPrec<T>::type;
+  LatConsts<HP> k;
+  const HP m0 = M.m0, m1 = Const::m1, m2 = M.m2, i1 = Const::I1, It = M.I2t, lc = M.lc, c0z = M.c0z, az = Const::anchor_z;
+  const HP mt = m0 + m1 + m2, imt = HP(1) / mt;
+  const HP a = m2 * lc, b = m0 * c0z + m1 * az + m2 * az;
+  const HP z2 = m0 * c0z * c0z + m1 * az * az;
+  k.base = i1 + It;
+  k.dI = HP(M.I2a) - It;
+  const HP mu = m2 * (mt - m2) * imt;
+  k.mul2 = mu * lc * lc;
+  const HP common = k.base + m2 * (lc * lc + az * az) - (a * a + b * b) * imt;
+  k.Kx = HP(M.I0x) + z2 + common;
+  k.Ky = HP(M.I0y) + z2 + common;
+  k.Kz = HP(M.I0z) + k.base + m2 * lc * lc - a * a * imt;
+  k.k2 = k.dI - k.mul2;
+  k.k3 = -m2 * lc * (az - b * imt);
+  k.b1c = k.base + k.mul2;
+  k.d2c = It + k.mul2;
+  k.kl = a * imt;
+  k.rz0 = b * imt;
+  k.imt = imt;
+  k.hb = HP(h) * HP(Const::damping);
+  k.e2 = HP(1) / (k.d2c + k.hb);
+  return k;
+}
+template <class HP>
+struct Inv5 {
+  HP cxx, cxy, cxz, cyy, cyz, czz;   // C
+  V3<HP> U1, U2;
+  HP s11, s12, s22;
+  V3<HP> rc, kp1, kp2;               // COM; (m2 / mt) (x, y2) x rho
+};
+// th: tether_hp() of the float32 sine / cosine pairs (unit to HP rounding)
+template <class HP>
+QD_HD Inv5<HP> mass_inverse(const LatConsts<HP>& k, const TetherHP<HP>& th) {
+  Inv5<HP> v;
+  const HP s1 = th.s1, c1 = th.c1, s2 = th.s2, c2 = th.c2;
+  const HP dx = th.d.x, dy = th.d.y, dz = th.d.z;
+  const HP k2x = k.k2 * dx, k2y = k.k2 * dy, k2z = k.k2 * dz, shift = HP(-2) * k.k3 * dz;
+  const HP Jxx = k.Kx + shift + k2x * dx, Jyy = k.Ky + shift + k2y * dy, Jzz = k.Kz + k2z * dz;
+  const HP Jxy = k2x * dy, Jxz = k2x * dz + k.k3 * dx, Jyz = k2y * dz + k.k3 * dy;
+  const HP w1 = k.b1c - k.k3 * dz, w2 = k.d2c - k.k3 * dz, k3s = k.k3 * s1;
+  const V3<HP> B1 = mk<HP>(w1 + k2x * dx, k2x * dy, k2x * dz);
+  const V3<HP> B2 = mk<HP>(k3s * dx, w2 * c1 + k3s * dy, w2 * s1 + k3s * dz);
+  const HP D1 = k.base + k.dI * s2 * s2 + k.mul2 * c2 * c2;
+  const HP e1 = frcp(D1 + k.hb), e2 = k.e2;
+  const V3<HP> E1 = e1 * B1, E2 = e2 * B2;
+  // J' = J - e1 B1 B1^T - e2 B2 B2^T
+  const HP Pxx = Jxx - E1.x * B1.x - E2.x * B2.x, Pxy = Jxy - E1.x * B1.y - E2.x * B2.y, Pxz = Jxz - E1.x * B1.z - E2.x * B2.z;
+  const HP Pyy = Jyy - E1.y * B1.y - E2.y * B2.y, Pyz = Jyz - E1.y * B1.z - E2.y * B2.z, Pzz = Jzz - E1.z * B1.z - E2.z * B2.z;
+  // adjugate
+  const HP a00 = Pyy * Pzz - Pyz * Pyz, a01 = Pxz * Pyz - Pxy * Pzz, a02 = Pxy * Pyz - Pxz * Pyy;
+  const HP a11 = Pxx * Pzz - Pxz * Pxz, a12 = Pxy * Pxz - Pxx * Pyz, a22 = Pxx * Pyy - Pxy * Pxy;
+  const HP idet = frcp(Pxx * a00 + Pxy * a01 + Pxz * a02);
+  v.cxx = a00 * idet; v.cxy = a01 * idet; v.cxz = a02 * idet; v.cyy = a11 * idet; v.cyz = a12 * idet; v.czz = a22 * idet;
+  v.U1 = mk<HP>(v.cxx * E1.x + v.cxy * E1.y + v.cxz * E1.z, v.cxy * E1.x + v.cyy * E1.y + v.cyz * E1.z, v.cxz * E1.x + v.cyz * E1.y + v.czz * E1.z);
+  v.U2 = mk<HP>(v.cxx * E2.x + v.cxy * E2.y + v.cxz * E2.z, v.cxy * E2.x + v.cyy * E2.y + v.cyz * E2.z, v.cxz * E2.x + v.cyz * E2.y + v.czz * E2.z);
+  v.s11 = e1 + dot(E1, v.U1); v.s12 = dot(E1, v.U2); v.s22 = e2 + dot(E2, v.U2);
+  v.rc = mk<HP>(k.kl * dx, k.kl * dy, k.kl * dz + k.rz0);
+  v.kp1 = mk<HP>(HP(0), -k.kl * dz, k.kl * dy);                                   // kl (x x d)
+  v.kp2 = mk<HP>(k.kl * (c1 * dz - s1 * dy), k.kl * (s1 * dx), -k.kl * (c1 * dx));  // kl (y2 x d)
+  return v;
+}
+// the damping-implicit generalised accelerations from the two wrenches (what reduce_rhs + finish_accel<true> give)
+template <class T, class HP>
+QD_HD void solve_inv5(const LatConsts<HP>& k, const Inv5<HP>& v, const Applied<T>& ap, const Inertial<HP>& in, V3<HP>* a0, V3<T>* ang, T* thdd1,
+                      T* thdd2) {
+  const V3<HP> fl = cvt<HP>(ap.F) - in.F;
+  const V3<HP> fw = cvt<HP>(ap.Tq) - in.Tq;
+  const HP ft1 = HP(ap.t1) - in.t1, ft2 = HP(ap.t2) - in.t2;
+  const V3<HP> fwr = fw - cross(v.rc, fl);
+  const HP g1 = ft1 - (v.kp1.y * fl.y + v.kp1.z * fl.z), g2 = ft2 - dot(v.kp2, fl);
+  const V3<HP> al = mk<HP>(v.cxx * fwr.x + v.cxy * fwr.y + v.cxz * fwr.z - g1 * v.U1.x - g2 * v.U2.x,
+                           v.cxy * fwr.x + v.cyy * fwr.y + v.cyz * fwr.z - g1 * v.U1.y - g2 * v.U2.y,
+                           v.cxz * fwr.x + v.cyz * fwr.y + v.czz * fwr.z - g1 * v.U1.z - g2 * v.U2.z);
+  const HP t1 = v.s11 * g1 + v.s12 * g2 - dot(v.U1, fwr), t2 = v.s12 * g1 + v.s22 * g2 - dot(v.U2, fwr);
+  *a0 = k.imt * fl - cross(al, v.rc) - t1 * v.kp1 - t2 * v.kp2;
+  *ang = cvt<T>(al); *thdd1 = T(t1); *thdd2 = T(t2);
+}
+
+// applied_wrench() in two halves, for two wavefronts: rotors + drag on core and link | drag on the tether.  Their sum is the
+// applied wrench (the order of the float32 additions differs from applied_wrench(): rounding-level differences).
+// CORE_INERTIAL: minus the core body's inertial wrench (weight in body axes gt = R^T (0,0,g), gyroscopic moment), in T
+template <bool CORE_INERTIAL = false, class T>
+QD_HD Applied<T> applied_core_link(const Model<T>& M, const State<T>& s, V3<T> w, V3<T> vb, T s1, T c1, V3<T> gt = V3<T>{T(0), T(0), T(0)}) {
+  const T f0 = M.gearF * s.a0, f1 = M.gearF * s.a1, f2 = M.gearF * s.a2, f3 = M.gearF * s.a3;
+  const V3<T> tT = mk<T>(M.rot * (-f0 + f1 + f2 - f3), M.rot * (-f0 - f1 + f2 + f3), M.gearT * (s.a0 - s.a1 + s.a2 - s.a3));
+  V3<T> fD0, tD0;
+  fluid(M.klin0, M.kang0, M.qlx0, M.qly0, M.qlz0, M.qax0, M.qay0, M.qaz0, w, mk<T>(vb.x + w.y * M.c0z, vb.y - w.x * M.c0z, vb.z), &fD0, &tD0);
+  const T az = T(Const::anchor_z);
+  const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
+  const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);
+  const T k1 = T(LinkFluid::klin), k2 = T(LinkFluid::kang), k3 = T(LinkFluid::ql), k4 = T(LinkFluid::qa);
+  V3<T> fl, tl;
+  fluid(k1, k2, k3, k3, k3, k4, k4, k4, mk<T>(w1.x, c1 * w1.y + s1 * w1.z, -s1 * w1.y + c1 * w1.z),
+        mk<T>(va.x, c1 * va.y + s1 * va.z, -s1 * va.y + c1 * va.z), &fl, &tl);
+  const V3<T> fD1 = mk<T>(fl.x, c1 * fl.y - s1 * fl.z, s1 * fl.y + c1 * fl.z);
+  const V3<T> tD1 = mk<T>(tl.x, c1 * tl.y - s1 * tl.z, s1 * tl.y + c1 * tl.z);
+  Applied<T> ap;
+  ap.F = mk<T>(fD0.x + fD1.x, fD0.y + fD1.y, (f0 + f1 + f2 + f3) + fD0.z + fD1.z);
+  ap.Tq = tT + tD0 + mk<T>(-M.c0z * fD0.y, M.c0z * fD0.x, T(0)) + tD1 + mk<T>(-az * fD1.y, az * fD1.x, T(0));
+  ap.t1 = tD1.x;
+  ap.t2 = T(0);
+  if (CORE_INERTIAL) {
+    const V3<T> u = mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y));
+    const V3<T> F0 = M.m0 * (gt + M.c0z * u);
+    const V3<T> N0 = mk<T>(w.y * w.z * (M.I0z - M.I0y), w.z * w.x * (M.I0x - M.I0z), w.x * w.y * (M.I0y - M.I0x));
+    ap.F = ap.F - F0;
+    ap.Tq = ap.Tq - N0 - mk<T>(-M.c0z * F0.y, M.c0z * F0.x, T(0));
+  }
+  return ap;
+}
+template <class T>
+QD_HD Applied<T> applied_tether(const Model<T>& M, const State<T>& s, V3<T> w, V3<T> vb, const Tether<T>& tg) {
+  const T az = T(Const::anchor_z);
+  const V3<T> d = tg.d, y2 = tg.y2, e_x = tg.e_x;
+  const V3<T> w1 = mk<T>(w.x + s.thd1, w.y, w.z);
+  const V3<T> w2 = w1 + s.thd2 * y2;
+  const V3<T> va = mk<T>(vb.x + w.y * az, vb.y - w.x * az, vb.z);
+  const V3<T> vc2 = va + M.lc * cross(w2, d);
+  V3<T> fl, tl;
+  fluid(M.klin2, M.kang2, M.qlt2, M.qlt2, M.qla2, M.qat2, M.qat2, M.qaa2,
+        mk<T>(dot(e_x, w2), dot(y2, w2), -dot(d, w2)), mk<T>(dot(e_x, vc2), dot(y2, vc2), -dot(d, vc2)), &fl, &tl);
+  const V3<T> fD2 = fl.x * e_x + fl.y * y2 - fl.z * d;
+  const V3<T> tD2 = tl.x * e_x + tl.y * y2 - tl.z * d;
+  const V3<T> t2v = tD2 + cross(M.lc * d, fD2);
+  Applied<T> ap;
+  ap.F = fD2;
+  ap.Tq = mk<T>(-az * fD2.y, az * fD2.x, T(0)) + t2v;
+  ap.t1 = t2v.x;
+  ap.t2 = dot(y2, t2v);
+  return ap;
+}
+// body-frame quantities both halves need: attitude matrix of the normalised quaternion and the origin velocity in body axes
+template <class T>
+QD_HD void attitude_min(const State<T>& s, M3<T>* R, V3<T>* vb) {
+  const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+  *R = quat2mat(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn);
+  *vb = mulT(*R, mk<T>(s.vx, s.vy, s.vz));
+}
+
+// The same forward dynamics composed from the latency pieces in one lane (implicit accelerations only; host twin test).
+template <class T>
+QD_HD void forward_lat(const Model<T>& M, const State<T>& s, T h, Accel<T>* im) {
+  using HP = typename HighPrec<T>::type;
+  M3<T> R;
+  V3<T> vb;
+  attitude_min(s, &R, &vb);
+  const V3<T> w = mk<T>(s.wx, s.wy, s.wz);
+  const Tether<T> tg = tether_geometry(s.th1, s.th2);
+  const T g = T(Const::gravity);
+  const Applied<T> a1 = applied_core_link<true>(M, s, w, vb, tg.s1, tg.c1, mk<T>(g * R.m20, g * R.m21, g * R.m22)), a2 = applied_tether(M, s, w, vb, tg);
+  Applied<T> ap;
+  ap.F = a1.F + a2.F; ap.Tq = a1.Tq + a2.Tq; ap.t1 = a1.t1 + a2.t1; ap.t2 = a1.t2 + a2.t2;
+  V3<T> gt, w_;
+  gravity_body(s, &gt, &w_);
+  const TetherHP<HP> th = tether_hp<HP>(tg.s1, tg.c1, tg.s2, tg.c2);
+  const Inertial<HP> in = inertial_wrench_hp<T, HP, false>(M, s, gt, w_, th.d, th.y2);
+  const LatConsts<HP> k = lat_consts(M, h);
+  const Inv5<HP> v = mass_inverse(k, th);
+  V3<HP> a0;
+  solve_inv5(k, v, ap, in, &a0, &im->ang, &im->thdd1, &im->thdd2);
+  im->lin = mul(R, cvt<T>(a0));
 }
 
 // The accelerometer reading as an affine function of the activations at a fixed state: reading(a) = c0 + sum_i a_i col_i.
@@ -599,6 +826,23 @@ QD_HD void integrate_act(const Model<T>& M, State<T>& s, T c0, T c1, T c2, T c3,
   const T ht = h * M.inv_tau;
   s.a0 += ht * (c0 - s.a0); s.a1 += ht * (c1 - s.a1); s.a2 += ht * (c2 - s.a2); s.a3 += ht * (c3 - s.a3);
 }
+// (w, x, y, z): the NORMALISED attitude; (wx, wy, wz): the new body rates.  q <- normalise(q (x) exp(h w / 2)) (mju_quatIntegrate).
+// Separate from integrate_motion() because the latency kernel normalises the old quaternion a phase ahead of the solve.
+template <class T>
+QD_HD void quat_advance(T w, T x, T y, T z, T wx, T wy, T wz, T h, T* ow, T* ox, T* oy, T* oz) {
+  const T w2 = wx * wx + wy * wy + wz * wz;
+  T ax = T(1), ay = T(0), az = T(0), ang = T(0);
+  if (w2 >= T(1e-30)) { const T iw = frsq(w2); ax = wx * iw; ay = wy * iw; az = wz * iw; ang = h * (w2 * iw); }
+  T sh, ch;
+  qsincos(T(0.5) * ang, &sh, &ch);
+  const T rx = ax * sh, ry = ay * sh, rz = az * sh;
+  const T nw = w * ch - x * rx - y * ry - z * rz;
+  const T nx = w * rx + x * ch + y * rz - z * ry;
+  const T ny = w * ry - x * rz + y * ch + z * rx;
+  const T nz = w * rz + x * ry - y * rx + z * ch;
+  const T qn = frsq(nw * nw + nx * nx + ny * ny + nz * nz);
+  *ow = nw * qn; *ox = nx * qn; *oy = ny * qn; *oz = nz * qn;
+}
 template <class T, bool LOAD>
 QD_HD void integrate_motion(State<T>& s, const Accel<T>& im, T h) {
   // velocities, then positions with the NEW velocities
@@ -611,20 +855,8 @@ QD_HD void integrate_motion(State<T>& s, const Accel<T>& im, T h) {
   }
   // quaternion exponential map with the body-frame rate, then renormalise
   {
-    T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
-    const T w = s.qw * qn, x = s.qx * qn, y = s.qy * qn, z = s.qz * qn;
-    const T w2 = s.wx * s.wx + s.wy * s.wy + s.wz * s.wz;
-    T ax = T(1), ay = T(0), az = T(0), ang = T(0);
-    if (w2 >= T(1e-30)) { const T iw = frsq(w2); ax = s.wx * iw; ay = s.wy * iw; az = s.wz * iw; ang = h * (w2 * iw); }
-    T sh, ch;
-    qsincos(T(0.5) * ang, &sh, &ch);
-    const T rx = ax * sh, ry = ay * sh, rz = az * sh;
-    const T nw = w * ch - x * rx - y * ry - z * rz;
-    const T nx = w * rx + x * ch + y * rz - z * ry;
-    const T ny = w * ry - x * rz + y * ch + z * rx;
-    const T nz = w * rz + x * ry - y * rx + z * ch;
-    qn = frsq(nw * nw + nx * nx + ny * ny + nz * nz);
-    s.qw = nw * qn; s.qx = nx * qn; s.qy = ny * qn; s.qz = nz * qn;
+    const T qn = frsq(s.qw * s.qw + s.qx * s.qx + s.qy * s.qy + s.qz * s.qz);
+    quat_advance(s.qw * qn, s.qx * qn, s.qy * qn, s.qz * qn, s.wx, s.wy, s.wz, h, &s.qw, &s.qx, &s.qy, &s.qz);
   }
 }
 template <class T, bool LOAD>

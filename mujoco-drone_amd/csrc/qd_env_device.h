@@ -651,6 +651,9 @@ __device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rh
 hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream,
                                bool pid = false, float* actions_out = nullptr);
 
+// qd_rollout_lat.hip: the same fragment for batches of at most 256 workgroups (every workgroup has a CU to itself), SPEC_RMA or
+// SPEC_GENERIC_FS1 with an observation variant that does not read the accelerometer; hipErrorInvalidValue otherwise
+hipError_t launch_rollout_lat(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 // SimpleDrone's fragments at small batches: a physics wave and an epilogue wave per 64 envs (qd_rollout_coop.hip)
 hipError_t launch_rollout_pair(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 // qd_step_floor.hip: one env step of a floor-contact configuration (SPEC_FLOOR), any batch size

@@ -824,7 +824,7 @@ struct qd_env {
   hipStream_t frag_stream = nullptr;
   // qd_set_reference_schedule: waypoint k is the reference of the k-th step of the next policy rollout
   std::vector<double> ref_schedule;
-  int opt[QD_OPT_COUNT] = {1};   // qd_set_option
+  int opt[QD_OPT_COUNT] = {1, 1};   // qd_set_option
 };
 
 static thread_local char g_err[512] = "";
@@ -1235,6 +1235,14 @@ static bool qd_fragment_is_persistent(const qd_env* env) {
   if (env->spec == SPEC_LSTM || env->spec == SPEC_GENERIC_FS1) return env->ka.n <= qd_persistent_max_envs() && env->ka.n <= qd_persistent_max_envs_other();
   return false;
 }
+// ... and of those, the batches that leave every workgroup a CU of its own (<= 256 workgroups) in the latency arrangement of the
+// same step (k_rollout_lat, qd_rollout_lat.hip): train_PPO.py / train_RMA.py's configuration and every run-time-dispatched one whose
+// observation row does not carry the accelerometer
+static bool qd_fragment_is_latency(const qd_env* env) {
+  if (!qd_fragment_is_persistent(env) || !env->opt[QD_OPT_LATENCY_KERNEL]) return false;
+  if (env->ka.n > 256 * 64) return false;
+  return env->spec == SPEC_RMA || (env->spec == SPEC_GENERIC_FS1 && !env->ka.obs_needs_acc);
+}
 // The single-body model (SimpleDrone, and BaseDroneEnv without the load): its step is ~500 float32 instructions, too short to be
 // worth a split over waves, so a fragment runs in k_rollout -- one wavefront per 64 envs, state in registers, rows through the
 // wave's LDS tile.  Measured against the per-step launches (tests/diag_rollout_simple.py, BASELINE config 2): 1.57 / 3.51 us per
@@ -1278,6 +1286,7 @@ const char* qd_fragment_kernel_name(const qd_env* env) {
     return buf;
   }
   if (!qd_fragment_is_persistent(env)) return qd_step_kernel_name(env);
+  if (qd_fragment_is_latency(env)) return env->spec == SPEC_RMA ? "qd::k_rollout_lat<1>" : "qd::k_rollout_lat<4>";
   const bool two = env->ka.n > 256 * 64;
   return env->spec == SPEC_RMA ? "qd::k_rollout_coop<1,2>"
        : env->spec == SPEC_LSTM ? (two ? "qd::k_rollout_coop<2,2>" : "qd::k_rollout_coop<2,1>")
@@ -1291,6 +1300,10 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
   if (!actions || !obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   const int n = env->ka.n;
   const size_t D = (size_t)env->D;
+  if (qd_fragment_is_latency(env)) {
+    QD_HIP(launch_rollout_lat(env->ka, env->spec, T, actions, obs, reward, truncated, S(stream)));
+    return QD_OK;
+  }
   if (qd_fragment_is_persistent(env)) {
     QD_HIP(launch_rollout_coop(env->ka, env->spec, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
@@ -1381,6 +1394,10 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
                              truncated + (size_t)t * k.n, stream);
       if (rc != QD_OK) return rc;
     }
+    return QD_OK;
+  }
+  if (qd_fragment_is_latency(env)) {
+    QD_HIP(launch_rollout_lat(k, env->spec, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
   if (qd_fragment_is_persistent(env)) {

@@ -466,6 +466,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       float ref_t[4];
       uint4 info = make_uint4(0u, 0u, 0u, 0u);
       bool rst = false;
+      float rw = 0.f;
       const bool row_now = t >= 1 && t <= T;   // the row of step t - 1 is the observation of s_t
       float* tile_now = L.tile[(t - 1) & 1];
       // PID: the action of step t - 1 (wave B published it in that round's phase 2)
@@ -483,27 +484,18 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
         if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
         drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
         write_obs_row<true, SPEC>(a, ed, sv, &Rq, tile_now + lane * D);
-      }
-      RC_STAMP(1);
-      if (t < rounds) coop_barrier();   // 1
-      else if (sens) coop_barrier();    // E: the reading at s_T is published
-      RC_STAMP(2);
-      V3<float> acc_new = mk<float>(0.f, 0.f, 0.f);
-      if (sens && t >= 1) {   // the reading of round t - 1 (wave A's phase 1 of this round); in the last iteration the one at s_T
-        const float4 x = (t == rounds) ? L.acc2[lane] : L.acc[lane];
-        acc_new = mk<float>(x.x, x.y, x.z);
-      }
-      if (row_now) {
+        // The reward of step t - 1, here and not behind barrier 1: for a truncated lane it is of the state BEFORE its reset, L.pre,
+        // which wave A rewrites in phase 2 of THIS round for the lanes that truncate in step t -- a lane that resets in two
+        // consecutive steps (max_steps <= 1, a start sampled outside max_distance) would otherwise race with its own next reset.
         const float act4[4] = {act_prev.x, act_prev.y, act_prev.z, act_prev.w};
         const bool simple = spec_term<SPEC>(a) == QD_TERM_SIMPLE;
-        float rw;
         if (simple) {   // SimpleDrone.step's reward on this model (env_step: 0.1 - |pos - ref|)
           const float dx = sv[0] - ref_t[0], dy = sv[1] - ref_t[1], dz = sv[2] - ref_t[2];
           rw = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
         } else {
           rw = reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
         }
-        if (__any(rst ? 1 : 0)) {   // the reward of a truncated lane is of the state BEFORE its reset
+        if (__any(rst ? 1 : 0)) {
           State<float> p;
           rc_get_state(L.pre, lane, p);
           float sv2[33];
@@ -518,11 +510,26 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
           }
           if (rst) rw = rw2;
         }
+      }
+      RC_STAMP(1);
+      if (t < rounds) coop_barrier();   // 1
+      else if (sens) coop_barrier();    // E: the reading at s_T is published
+      RC_STAMP(2);
+      V3<float> acc_new = mk<float>(0.f, 0.f, 0.f);
+      if (sens && t >= 1) {   // the reading of round t - 1 (wave A's phase 1 of this round); in the last iteration the one at s_T
+        const float4 x = (t == rounds) ? L.acc2[lane] : L.acc[lane];
+        acc_new = mk<float>(x.x, x.y, x.z);
+      }
+      if (row_now) {
         if (live) {
           __builtin_nontemporal_store(rw, reward_out + (size_t)(t - 1) * n + i);
           __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc_out + (size_t)(t - 1) * n + i);
         }
-        if (!sens) flush_obs_any<SPEC>(tile_now, obs + ((size_t)(t - 1) * n + base_env) * D, rows, D);
+        if (!sens) {
+          // the tile was written by this wave's own lanes in phase 1; in the last iteration no workgroup barrier lies between
+          if (t == rounds) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+          flush_obs_any<SPEC>(tile_now, obs + ((size_t)(t - 1) * n + base_env) * D, rows, D);
+        }
       }
       if (sens && t >= 2) {   // row t - 2: its sensor entries are final now
         float* tile_then = L.tile[t & 1];

@@ -15,6 +15,9 @@ from mujoco_drone_amd import parallel as par  # noqa: E402
 
 N, T = int(os.environ.get("QD_DIAG_ENVS", 4096)), int(sys.argv[1]) if len(sys.argv) > 1 else 256
 env, _ = bench.make_env("config3", N, 42, "cuda:0")
+if os.environ.get("QD_DIAG_LATENCY") == "0":
+    from mujoco_drone_amd import _lib as QL
+    env._dev.set_option(QL.OPT_LATENCY_KERNEL, 0)
 env.vector_reset_tensor()
 f = par.FragmentBuffers(T, N, env._dev.D, "cuda:0")
 f.actions.copy_(torch.rand(f.actions.shape, device="cuda"))
@@ -30,13 +33,14 @@ for rep in range(24):
     else:
         env.step_fragment_tensor(f.actions, f.obs, f.rewards, f.truncated)
     torch.cuda.synchronize()
-    assert lib.qd_debug_read_rcstamps(buf) == 0
+    reader = lib.qd_debug_read_rlstamps if "k_rollout_lat" in env._dev.fragment_kernel_name() else lib.qd_debug_read_rcstamps
+    assert reader(buf) == 0
     st = np.array(buf[:], dtype=np.int64).reshape(64, 4, 16)[:, :, :5]
     acc.append(st - st[:, :1, :1])            # relative to wave A's start of the stamped step
 acc = np.array(acc).reshape(-1, 4, 5)
 med = np.median(acc, axis=0)
 names = ["step start (after barrier 2)", "phase 1 done", "barrier 1 passed", "phase 2 done", "barrier 2 passed"]
-print("k_rollout_coop%s, step T/2 of a %d-step fragment, %d envs: median cycles since wave A's step start (waves A / B / C / D)" % (" (PID cascade in wave B's phase 2)" if PID else "", T, N))
+print("%s%s, step T/2 of a %d-step fragment, %d envs: median cycles since wave A's step start (waves A / B / C / D)" % (env._dev.fragment_kernel_name(), " (PID cascade in wave B's phase 2)" if PID else "", T, N))
 for k, nm in enumerate(names):
     print("  %-30s %7.0f %7.0f %7.0f %7.0f" % (nm, med[0, k], med[1, k], med[2, k], med[3, k]))
 per = acc[:, 0, 4] - acc[:, 0, 0]

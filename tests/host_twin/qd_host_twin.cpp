@@ -245,6 +245,32 @@ void twin_forward_pair_f32(const double* model16, const double* qpos, const doub
 }
 }
 
+// ---- the latency-bound kernel's arrangement of the same equations (lat_consts / mass_inverse / solve_inv5, split applied wrench) ----
+template <class T>
+static void fwd_lat(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out8) {
+  Model<T> M;
+  T* mp = reinterpret_cast<T*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = (T)model16[i];
+  State<T> s;
+  s.px = qpos[0]; s.py = qpos[1]; s.pz = qpos[2]; s.qw = qpos[3]; s.qx = qpos[4]; s.qy = qpos[5]; s.qz = qpos[6];
+  s.th1 = qpos[7]; s.th2 = qpos[8];
+  s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
+  s.thd1 = qvel[6]; s.thd2 = qvel[7];
+  s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
+  Accel<T> im;
+  forward_lat<T>(M, s, (T)h, &im);
+  out8[0] = im.lin.x; out8[1] = im.lin.y; out8[2] = im.lin.z; out8[3] = im.ang.x; out8[4] = im.ang.y; out8[5] = im.ang.z;
+  out8[6] = im.thdd1; out8[7] = im.thdd2;
+}
+extern "C" {
+void twin_forward_lat_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out8) {
+  fwd_lat<double>(model16, qpos, qvel, act, h, out8);
+}
+void twin_forward_lat_f32(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out8) {
+  fwd_lat<float>(model16, qpos, qvel, act, h, out8);
+}
+}
+
 // ---- accelerometer as an affine function of the activations (reset pool) vs forward() at those activations ----
 extern "C" {
 void twin_sensor_affine_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out6) {

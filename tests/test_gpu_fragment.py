@@ -84,6 +84,32 @@ def test_fragment_equals_per_step_kernel(qd, n):
     assert int(Tr.sum()) > 0
 
 
+@pytest.mark.parametrize("n", [300, 4097, 40001])
+def test_fragment_with_a_reset_in_every_step(qd, n):
+    """max_steps = 1: every lane truncates and is reset in EVERY step, so the reward of step t - 1 (of the state before that
+    step's reset, handed over in LDS) is due while the solver wave already publishes step t's pre-reset state.  Rewards, rows and
+    flags against the per-step kernel, and twice in a row against itself (a race would make the launch irreproducible)."""
+    L = qd._lib
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, random_params=1, auto_reset=1, max_steps=1, seed=3))
+    a, b, c = mk(), mk(), mk()
+    for e in (a, b, c):
+        e.reset()
+    T = 24
+    acts = torch.rand((T, n, 4), generator=torch.Generator(device="cuda").manual_seed(n), device="cuda")
+    O, R, Tr = _bufs(T, n)
+    a.step_fragment(acts, O, R, Tr)
+    O2, R2, Tr2 = _bufs(T, n)
+    c.step_fragment(acts, O2, R2, Tr2)
+    assert torch.equal(O, O2) and torch.equal(R, R2) and torch.equal(Tr, Tr2)
+    w = _Worst()
+    for t in range(T):
+        o, r, tr = b.step(acts[t])
+        w.step(O[t], o, R[t], r, Tr[t], tr, "t %d" % t)
+    w.states(a, b, "after %d steps" % T)
+    assert int(Tr.sum()) == T * n
+    print("n = %d, a reset in every step: fragment vs per-step kernel, %s" % (n, w))
+
+
 @pytest.mark.parametrize("N", [4097, 40001])
 def test_fragment_is_batch_and_cut_invariant(qd, N):
     """what must hold bit for bit: env i's rows do not depend on the batch it is in (N envs vs the first 64 of them alone) nor
@@ -92,6 +118,9 @@ def test_fragment_is_batch_and_cut_invariant(qd, N):
     L, T = qd._lib, 40
     mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, start=1, random_params=1, auto_reset=1, max_steps=7, seed=9))
     big, small, cut = mk(N), mk(64), mk(N)
+    if N > 16384:   # bit-exactness holds within one kernel: above 16384 envs that is k_rollout_coop, so the 64-env batch runs it too
+        small.set_option(L.OPT_LATENCY_KERNEL, 0)
+    assert big.fragment_kernel_name() == small.fragment_kernel_name() == cut.fragment_kernel_name()
     for e in (big, small, cut):
         e.reset()
     acts = torch.rand((T, N, 4), device="cuda")
@@ -115,6 +144,27 @@ def test_fragment_is_batch_and_cut_invariant(qd, N):
         if N > 16384 and name.startswith(("NX", "NY")):           # run the in-workgroup sampler (above 16384 envs lanes sample inline:
             continue                                              # same states, nothing left in the pool planes)
         assert torch.equal(pb[k], ps[k]), "arena plane %s" % name
+
+
+def test_latency_and_throughput_kernels_agree(qd):
+    """the two persistent kernels (k_rollout_lat up to 16384 envs, k_rollout_coop above, QD_OPT_LATENCY_KERNEL = 0 everywhere) run
+    the same step in two arrangements of the same equations (qd_dynamics.h: mass_inverse / solve_inv5 against mass_factor /
+    reduce_rhs / finish_accel): flags identical, values to rounding over short episodes, the state left behind likewise"""
+    L, n, T = qd._lib, 3000, 40
+    mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, start=1, random_params=1, auto_reset=1, max_steps=9, seed=4))
+    a, b = mk(), mk()
+    b.set_option(L.OPT_LATENCY_KERNEL, 0)
+    assert "k_rollout_lat<1>" in a.fragment_kernel_name() and "k_rollout_coop<1" in b.fragment_kernel_name()
+    a.reset(); b.reset()
+    acts = torch.rand((T, n, 4), generator=torch.Generator(device="cuda").manual_seed(5), device="cuda")
+    (Oa, Ra, Ta), (Ob, Rb, Tb) = _bufs(T, n), _bufs(T, n)
+    a.step_fragment(acts, Oa, Ra, Ta)
+    b.step_fragment(acts, Ob, Rb, Tb)
+    w = _Worst()
+    for t in range(T):
+        w.step(Oa[t], Ob[t], Ra[t], Rb[t], Ta[t], Tb[t], "t %d" % t)
+    w.states(a, b, "after %d steps" % T)
+    print("k_rollout_lat vs k_rollout_coop: %s" % w)
 
 
 def test_fragment_and_per_step_launches_interleave(qd):
@@ -360,14 +410,16 @@ def test_config5_fragment_is_batch_and_cut_invariant(qd):
                                                ("GlobalFrameRPYEnv", "reward_pendulumDistHeading", None),
                                                ("LocalFrameRmParamsEnv", "reward_3", None)])
 def test_generic_fragment_equals_per_step_kernel(qd, obs, reward, acc_at):
-    """k_rollout_coop<SPEC_GENERIC_FS1>: any observation variant / reward of the load model, dispatched at run time in the epilogue
-    wave, with and without the accelerometer in the row; against the per-step kernel k_step<true,64,4>"""
+    """k_rollout_coop<SPEC_GENERIC_FS1> / k_rollout_lat<SPEC_GENERIC_FS1>: any observation variant / reward of the load model,
+    dispatched at run time in the epilogue waves, with and without the accelerometer in the row; against the per-step kernel
+    k_step<true,64,4>"""
     L, n, T = qd._lib, 700, 30
     mk = lambda: qd.dev.DeviceEnv(make_cfg(L, n, load=True, obs=obs, reward=reward, start=1, random_params=1, auto_reset=1,
                                              max_steps=8, seed=17))
     a, b = mk(), mk()
     a.reset(); b.reset()
-    assert "k_rollout_coop<4" in a.fragment_kernel_name(), a.fragment_kernel_name()
+    # rows that carry the accelerometer: k_rollout_coop's run-time-dispatched instantiation; the others, at this size, k_rollout_lat's
+    assert ("k_rollout_coop<4" if acc_at is not None else "k_rollout_lat<4>") in a.fragment_kernel_name(), a.fragment_kernel_name()
     D = a.D
     g = torch.Generator(device="cuda").manual_seed(2)
     for rep in range(2):

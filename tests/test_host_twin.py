@@ -345,6 +345,41 @@ def test_cooperative_pieces_equal_the_monolithic_forward(twin):
     assert worst32 < 5e-5
 
 
+def test_latency_pieces_equal_the_monolithic_forward(twin):
+    """qd_dynamics.h's third arrangement of the load model's forward dynamics, the one k_rollout_lat runs: inertia assembled from
+    per-env coefficients of the tether direction (lat_consts), hinges eliminated first, the 3x3 inverted by its adjugate and kept
+    as the symmetric inverse of the 5x5 rotational + hinge system (mass_inverse / solve_inv5), the applied wrench in two halves
+    (applied_core_link + applied_tether).  Same equations: the damping-implicit accelerations equal forward()'s to 1e-11 in
+    float64; with float32 state / trigonometry / drag and float64 algebra (what the device runs) both are compared with the
+    float64 value."""
+    rng = np.random.default_rng(79)
+    worst64, worst32, mono32 = 0.0, 0.0, 0.0
+    for k in range(600):
+        raw = rand_raw(rng, 1)
+        m28 = np.zeros(28)
+        assert twin.twin_derive(P(raw), P(m28)) == 1
+        qpos = np.zeros(9); qpos[:3] = rng.uniform(-2, 2, 3) + [0, 0, 15]
+        q = rng.normal(size=4); qpos[3:7] = q / np.linalg.norm(q) * rng.uniform(0.9, 1.1)
+        qpos[7:] = rng.normal(0, 0.8, 2)
+        qvel = np.concatenate([rng.normal(0, 3, 3), rng.normal(0, 4, 3), rng.normal(0, 3, 2)])
+        act = rng.uniform(-0.1, 1.2, 4)
+        o64, o32, l64, l32 = np.zeros(38), np.zeros(38), np.zeros(8), np.zeros(8)
+        twin.twin_forward_pair_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o64))
+        twin.twin_forward_pair_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o32))
+        twin.twin_forward_lat_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l64))
+        twin.twin_forward_lat_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l32))
+        scale = np.maximum(1.0, np.abs(o64[8:16]))
+        worst64 = max(worst64, float(np.max(np.abs(o64[8:16] - l64) / scale)))
+        worst32 = max(worst32, float(np.max(np.abs(l32 - o64[8:16]) / scale)))
+        mono32 = max(mono32, float(np.max(np.abs(o32[8:16] - o64[8:16]) / scale)))
+    print("latency pieces vs forward() in float64: %.2e; in float32 against the float64 value: %.2e (forward() in float32: %.2e)" % (worst64, worst32, mono32))
+    assert worst64 < 1e-11
+    # float32 inputs: both arrangements are judged against the float64 accelerations.  The latency pieces put the float32 sine /
+    # cosine pairs back on the unit circle in float64 (trig_unit) and come out closer than forward(), whose J and B D^-1 B^T see
+    # the pairs as they are (measured 7.7e-5 against 1.7e-4 over 2000 states)
+    assert worst32 < 2e-4 and worst32 <= 1.5 * mono32
+
+
 def test_sensor_is_affine_in_the_activations(twin):
     """sensor_affine (qd_dynamics.h): c0 + sum a_i col_i equals the accelerometer of forward() at the same state and
     activations -- what lets the reset pool prepare a new episode's first sensor reading before the activations are known"""
