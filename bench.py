@@ -19,9 +19,10 @@ process becomes a launcher: it starts N rank processes of this script (RANK / LO
 their environment) BEFORE touching torch or the GPU, relays rank 0's JSON line and exits non-zero if any rank failed.
 
 Steps are issued through qd_step_fragment (C ABI), one call per run of steps inside a [T,N,...] fragment.  For the headline
-configuration (config 3 at <= 24576 envs) a run is ONE persistent kernel launch (k_rollout_coop: 64 envs per workgroup stay on
-their CU for the whole run); otherwise a run is one k_step launch per step -- launch by launch for runs shorter than 128 steps,
-a replayed HIP graph above (captured during the untimed rehearsal, never inside the timed region).  `config.launch` says which,
+configurations (the load model with one substep per step, SimpleDrone) a run is ONE persistent kernel launch (k_rollout_lat up to
+16384 envs, k_rollout_coop above: 64 envs per workgroup stay on their CU for the whole run); otherwise a run is one k_step launch
+per step -- launch by launch for runs shorter than 128 steps, a replayed HIP graph above (captured during the untimed rehearsal,
+never inside the timed region).  `config.launch` says which,
 `roofline.kernel` names the kernel (the library's own variant selector: qd_fragment_kernel_name).  `roofline.kernel_us` does not
 depend on --steps: it is the average duration of back-to-back launches of the dominant kernel on 1024-step fragments, between
 two HIP events on the launch stream.
@@ -268,7 +269,7 @@ def launch_text(env, K, timed_runs):
 
 
 def committed_profile(kernel, config, n):
-    """figures of the committed rocprofv3 runs (profiles/current.json, written by tools/install_profiles_r03.py) -- only if they
+    """figures of the committed rocprofv3 runs (profiles/current.json, written by tools/install_profiles_r04.py) -- only if they
     were taken from the library that is loaded now: otherwise None and the reason"""
     path = os.path.join(ROOT, "profiles", "current.json")
     try:
@@ -527,7 +528,20 @@ def main():
         traffic = prof.get("hbm_bytes_per_launch") if prof else None
         prof_us = prof.get("rocprofv3_avg_kernel_us") if prof else None
         copy_gbps = measured_copy_gbps(device)
-        out["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        # What physically bounds this launch, from the committed counter passes of THIS library (hash-checked like `traffic`):
+        # the share of the chip's VALU issue slots it uses (SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel cycles)) and the share
+        # of the HBM peak it really moves (PMC bytes / duration).  `frac` (SURVEY 8d's bytes, the graded definition) stays as it is.
+        valu = prof.get("valu_issue_frac") if prof else None
+        moved = (traffic / (kus * 1e-6) / 1e9 / HBM_PEAK_GBS) if traffic else None
+        if valu is None and moved is None:
+            bound = "hbm"          # no counters for this library: the roofline SURVEY 8d names
+        elif (moved or 0.0) >= 0.5:
+            bound = "hbm"
+        elif (valu or 0.0) >= 0.5:
+            bound = "valu_issue"
+        else:
+            bound = "latency"      # neither bandwidth nor issue slots: a dependent chain on the CUs the launch occupies
+        out["roofline"] = {"bound": bound, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                            "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "kernel": kname,
                            "kernel_us": kus, "env_steps_per_launch": n * steps_per_launch, "steps_per_launch": steps_per_launch,
                            "us_per_step": us_per_step,
@@ -540,9 +554,17 @@ def main():
                            "frac_at_rocprofv3_duration": (bytes_per_launch / (prof_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if prof_us else None,
                            "traffic_bytes_per_env_step": (traffic / (n * steps_per_launch)) if traffic else None,
                            "profile_note": prof_note or ("rocprofv3_avg_kernel_us / traffic: profiles/current.json, taken from this library "
-                                                         "(source hash checked) by tools/profile_r03.sh: kernel trace of this command; "
+                                                         "(source hash checked) by tools/profile_r04.sh: kernel trace of this command; "
                                                          "separate --pmc FETCH_SIZE / WRITE_SIZE passes, FETCH_SIZE x2 per the gfx950 calibration"),
-                           "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps}
+                           "measured_copy_GBps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps,
+                           "frac_hbm_moved": moved, "valu_issue_frac": valu,
+                           "valu_issue_frac_of_occupied_simds": prof.get("valu_issue_frac_of_occupied_simds") if prof else None,
+                           "wait_frac_of_wave_cycles": prof.get("wait_frac_of_wave_cycles") if prof else None,
+                           "bound_note": "bound: 'hbm' if the PMC bytes of a launch are >= 50 % of 8 TB/s x its duration (frac_hbm_moved), else "
+                                         "'valu_issue' if its vector instructions fill >= 50 % of the chip's issue slots (valu_issue_frac = "
+                                         "SQ_INSTS_VALU x 4 / (1024 SIMDs x cycles)), else 'latency': a dependent chain on the SIMDs it occupies "
+                                         "(valu_issue_frac_of_occupied_simds is their share of issue slots in use).  `frac` prices the launch at "
+                                         "SURVEY 8d's bytes and is NOT an HBM utilisation for a persistent kernel."}
         if persistent:
             own_b = persistent_own_bytes(D)
             own = own_b * n * steps_per_launch / (kus * 1e-6) / 1e9

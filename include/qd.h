@@ -218,6 +218,11 @@ const char* qd_fragment_kernel_name(const qd_env* env);
  * or no entry yet).  Same results either way; inline sampling is what the pool exists to keep off the step's critical path.
  * counters: 2 x uint32 in device memory, written in stream order. */
 int qd_pool_counters(qd_env* env, uint32_t* counters, void* stream);
+/* Events that must not happen, counted since qd_init: counters[0] = hand-overs inside a kernel whose bounded poll ran out (the closed
+ * policy loop's row wave waits for the solver wave's publication; a run-out would mean wrong rows handed on).  Zero on a healthy
+ * run; the GPU tests assert it.  counters: QD_HEALTH_COUNTERS x uint32 in device memory, written in stream order. */
+#define QD_HEALTH_COUNTERS 1
+int qd_health_counters(qd_env* env, uint32_t* counters, void* stream);
 /* T consecutive steps in ONE launch with the state held on the chip: actions[T,N,4] ->
  * obs[T,N,D], reward[T,N], truncated[T,N].  Same results as T qd_step calls (up to rounding between kernels).  The persistent
  * kernel of qd_step_fragment where that applies, else k_rollout (one wavefront per 64 envs, state in registers). */
@@ -237,9 +242,10 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
  * qd_rollout_pid : T closed-loop steps (controller -> vector_step) in ONE launch: obs[T,N,D],
  *                  reward[T,N], truncated[T,N], actions_out[T,N,4] (nullable).  Same results as
  *                  T x (qd_pid_action, qd_step).  QD_ERR_UNSUPPORTED for SimpleDrone configurations.
- *                  Envs with floor_contact run the same loop launch by launch (the contact solve needs the
- *                  register file a multi-step kernel would keep the state in) and require actions_out as
- *                  the buffer between controller and step; qd_rollout steps such envs launch by launch too. */
+ *                  Envs with floor_contact, and load-model envs outside the persistent kernel (several substeps
+ *                  per step, QD_OPT_PERSISTENT_FRAGMENTS = 0), run the same loop launch by launch and require
+ *                  actions_out as the buffer between controller and step (QD_ERR_INVALID without it);
+ *                  qd_rollout steps such envs launch by launch too. */
 int qd_pid_reset(qd_env* env, const uint8_t* mask, void* stream);
 int qd_pid_action(qd_env* env, float* actions, void* stream);
 int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* truncated, float* actions_out,

@@ -104,6 +104,7 @@ SIGNATURES = {
     "qd_rollout": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "qd_step_fragment": (_I, [_VP, _VP, _I, _VP, _VP, _VP, _VP]),
     "qd_set_option": (_I, [_VP, _I, _I]),
+    "qd_health_counters": (_I, [_VP, _VP, _VP]),
     "qd_step_kernel_name": (C.c_char_p, [_VP]),
     "qd_fragment_kernel_name": (C.c_char_p, [_VP]),
     "qd_pool_counters": (_I, [_VP, _VP, _VP]),

@@ -113,9 +113,11 @@ def _compile_and_link(out, hash_define, flags, verbose=False):
                 print(" ".join(cmd), flush=True)
             procs.append((cmd, subprocess.Popen(cmd)))
             objs.append(obj)
-        for cmd, p in procs:
-            if p.wait() != 0:
-                raise subprocess.CalledProcessError(p.returncode, cmd)
+        # every compiler is waited for before anything is raised: the temporary directory is deleted on the way out, and a sibling
+        # still writing its object there would fail for a reason that is not its own
+        failed = [(cmd, p.returncode) for cmd, p in procs if p.wait() != 0]
+        if failed:
+            raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
         subprocess.check_call([hip, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs)
 
 

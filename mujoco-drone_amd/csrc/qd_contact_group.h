@@ -464,13 +464,7 @@ __device__ __forceinline__ void cg_solve(CgLds& G, CgWave& W, int base, int tota
       for (int k = 0; k < NV; k++) xk[k] = 0.0;
       double ck = cg_sum8(my_cost(xk));
       if (threadIdx.x < 64) SF_STAMP(11);
-#ifdef QD_CG_STATS
-      int st_it = 0, st_ls = 0;
-#endif
       for (int it = 0; it < 80; it++) {
-#ifdef QD_CG_STATS
-        st_it++;
-#endif
         double g[NV], H[NT];
 #pragma unroll
         for (int k = 0; k < NV; k++) g[k] = 0.0;
@@ -549,9 +543,6 @@ __device__ __forceinline__ void cg_solve(CgLds& G, CgWave& W, int base, int tota
 #pragma unroll
           for (int k = 0; k < NV; k++) xn[k] = xk[k] + t * dx[k];
           cn = cg_sum8(my_cost(xn)) + quad(xn);
-#ifdef QD_CG_STATS
-          st_ls++;
-#endif
           if (cn <= ck + 1e-4 * t * slope) break;
           t *= 0.5;
         }
@@ -569,10 +560,6 @@ __device__ __forceinline__ void cg_solve(CgLds& G, CgWave& W, int base, int tota
         ck = cn;
       }
       if (threadIdx.x < 64) SF_STAMP(12);
-#ifdef QD_CG_STATS
-      if (blockIdx.x < 2 && sub == 0 && grp < 2) printf("cg: block %d wave-base %d group %d: %d contacts (%d active), %d Newton iterations, %d cost evaluations, fz %.4f\n",
-                                                        (int)blockIdx.x, base, grp, ncon, nact, st_it, st_ls, fz);
-#endif
       if (fz > 0.0) {
 #pragma unroll
         for (int k = 0; k < NV; k++) qa[k] = r.a0[k] + xk[k];

@@ -140,6 +140,17 @@ QD_HD Tether<T> tether_geometry(T th1, T th2) {
   return t;
 }
 
+// the same from the two sine / cosine pairs (the latency kernel computes them once per step, in the solver wave)
+template <class T>
+QD_HD Tether<T> tether_from_trig(T s1, T c1, T s2, T c2) {
+  Tether<T> t;
+  t.s1 = s1; t.c1 = c1; t.s2 = s2; t.c2 = c2;
+  t.d = mk<T>(-t.s2, t.s1 * t.c2, -t.c1 * t.c2);
+  t.y2 = mk<T>(T(0), t.c1, t.s1);
+  t.e_x = mk<T>(t.c2, t.s1 * t.s2, -t.c1 * t.s2);
+  return t;
+}
+
 // applied wrench: rotor thrust + inertia-box fluid drag on the three bodies, reduced to
 //   F  total force, Tq total torque about the body origin (both F0 axes), t1 / t2 hinge torques
 template <class T>

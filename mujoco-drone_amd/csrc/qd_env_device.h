@@ -29,7 +29,8 @@ enum Group {
   NUM_GROUPS
 };
 constexpr int RAW_PLANES = 6;
-constexpr int POOL_STAT_WORDS = 64;   // behind the refill counters: [0] in-kernel resets served by the pool, [1] sampled inline (qd_pool_counters)
+constexpr int POOL_STAT_WORDS = 64;   // behind the refill counters: [0] in-kernel resets served by the pool, [1] sampled inline (qd_pool_counters);
+                                      // [8 + k]: events that must not happen (qd_health_counters): k = 0 a bounded in-kernel poll ran out
 constexpr int PAD = 256;
 
 struct KArgs {
@@ -76,6 +77,11 @@ __device__ __forceinline__ void pool_request(const KArgs& a, int i) {
 // bookkeeping of how in-kernel resets got their state (a handful of atomics per launch: only truncating lanes come here)
 __device__ __forceinline__ void pool_count(const KArgs& a, bool taken) {
   __hip_atomic_fetch_add((need_ptr)a.need + (a.npad >> 6) + (taken ? 0 : 1), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// an event that must not happen, counted where the host can see it (qd_health_counters)
+__device__ __forceinline__ void health_count(const KArgs& a, int which) {
+  __hip_atomic_fetch_add((need_ptr)a.need + (a.npad >> 6) + 8 + which, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // Compile-time specialisations of the fused step for the configurations the reference trains with; every other
@@ -612,9 +618,6 @@ __device__ __forceinline__ float4 pid_env_action(PidState<float>& c, const EnvRe
 }
 
 // ---- pieces the persistent role kernels share (qd_rollout_coop.hip, qd_rollout_fused.hip) ----
-#ifndef RC_PRE
-#define RC_PRE true
-#endif
 // The part of the Euler step that reads the action: the reference's ctrl map (BaseDroneEnv.step: 0.1 + 0.9 u for the training
 // configurations), MuJoCo's clamp to the ctrl range, and the activation filter.  One definition: the persistent kernels apply it in
 // several waves (to the solver's state, to the thrust wave's copy, to rows that carry the activations) and must agree bit for bit.
@@ -638,7 +641,7 @@ __device__ __forceinline__ void rc_pin(const V3<double>& v) { rc_pin(v.x, v.y, v
 __device__ __forceinline__ V3<float> rc_sensor(const Factor<double>& f, const Rhs<double>& r, const M3<float>& R, V3<float> w0) {
   Accel<float> ex;
   V3<double> a0ex;
-  finish_accel<false, RC_PRE>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
+  finish_accel<false, true>(f, r, &a0ex, &ex.ang, &ex.thdd1, &ex.thdd2);
   const float g = float(Const::gravity);
   return accelerometer(cvt<float>(a0ex), ex.ang, mk<float>(g * R.m20, g * R.m21, g * R.m22),
                        mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));

@@ -1213,9 +1213,8 @@ int qd_step(qd_env* env, const float* actions, int64_t n_action_values, float* o
   return QD_OK;
 }
 
-// does a fragment of this env run as one persistent launch (k_rollout_coop)?  The same batches k_step_coop steps: the
-// four-wave workgroup per 64 envs needs a CU to itself
-// Every batch size: measured against the per-step launches on one box (tests/diag_persistent_big.py, profiles/r03_persistent_vs_per_step.txt)
+// does a fragment of this env run as one persistent launch (k_rollout_lat / k_rollout_coop)?  The load model with one substep per step,
+// at every batch size: measured against the per-step launches on one box (tests/diag_persistent_big.py, profiles/r03_persistent_vs_per_step.txt)
 // 4096 envs 1.50 / 3.99 us per step, 16384 1.60 / 5.12, 65536 5.19 / 7.71, 262144 20.5 / 23.5, 2^20 73.2 / 70.9, 2^22 249 / 289.
 // QD_PERSISTENT_MAX_ENVS lowers the limit for experiments.
 static int qd_persistent_max_envs() {
@@ -1379,6 +1378,13 @@ int qd_pool_counters(qd_env* env, uint32_t* counters, void* stream) {
   return QD_OK;
 }
 
+int qd_health_counters(qd_env* env, uint32_t* counters, void* stream) {
+  QD_NEED(env);
+  if (!counters) return fail(QD_ERR_INVALID, "null output");
+  QD_HIP(hipMemcpyAsync(counters, env->ka.need + (env->ka.npad >> 6) + 8, QD_HEALTH_COUNTERS * sizeof(uint32_t), hipMemcpyDeviceToDevice, S(stream)));
+  return QD_OK;
+}
+
 int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* reward, uint8_t* truncated, void* stream) {
   QD_NEED(env);
   const KArgs& k = env->ka;
@@ -1408,18 +1414,24 @@ int qd_rollout(qd_env* env, const float* actions, int T, float* obs, float* rewa
     QD_HIP(launch_rollout_pair(k, T, actions, obs, reward, truncated, S(stream)));
     return QD_OK;
   }
-  const dim3 grid(blocks64(k.n)), block(64);
-#define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout<LOADV, 64, SPECV>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated)
   if (env->load) {
-    if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
-    else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
-    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
-    else QD_ROLL(true, SPEC_GENERIC);
-  } else {
-    if (env->spec == SPEC_SIMPLE) QD_ROLL(false, SPEC_SIMPLE);
-    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
-    else QD_ROLL(false, SPEC_GENERIC);
+    // The load model outside the persistent kernels (several substeps per step, or QD_OPT_PERSISTENT_FRAGMENTS = 0): launch by
+    // launch.  The one-wavefront multi-step kernel that used to run here kept the whole model and state alive across the float64
+    // core -- 400-418 registers, every second one an AGPR copy, 4-34 spills (profiles/r03_kernel_resources.txt) -- for
+    // configurations no training script of the reference uses (skip_steps = 1 throughout); it was removed in round 4.
+    const size_t D = (size_t)env->D;
+    for (int t = 0; t < T; t++) {
+      const int rc = qd_step(env, actions + (size_t)t * k.n * 4, (int64_t)k.n * 4, obs + (size_t)t * k.n * D, reward + (size_t)t * k.n,
+                             truncated + (size_t)t * k.n, stream);
+      if (rc != QD_OK) return rc;
+    }
+    return QD_OK;
   }
+  const dim3 grid(blocks64(k.n)), block(64);
+#define QD_ROLL(SPECV) QD_LAUNCH((k_rollout<false, 64, SPECV>), grid, block, 0, S(stream), k, T, actions, obs, reward, truncated)
+  if (env->spec == SPEC_SIMPLE) QD_ROLL(SPEC_SIMPLE);
+  else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(SPEC_GENERIC_FS1);
+  else QD_ROLL(SPEC_GENERIC);
 #undef QD_ROLL
   QD_LAUNCH_CHECK();
   return QD_OK;
@@ -1450,9 +1462,10 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
   if (T == 0) return QD_OK;
   if (!obs || !reward || !truncated) return fail(QD_ERR_INVALID, "null array argument");
   if (env->ka.term_kind == QD_TERM_SIMPLE) return fail(QD_ERR_UNSUPPORTED, "the PID cascade drives BaseDroneEnv models (attitude_test.py), not SimpleDrone");
-  if (env->spec == SPEC_FLOOR) {
-    // floor contact: launch by launch (see qd_rollout) -- controller, step, and fresh controllers for the envs that were re-sampled
-    if (!actions_out) return fail(QD_ERR_INVALID, "a floor-contact PID rollout runs launch by launch and needs actions_out [T,N,4] as its action buffer");
+  if (env->spec == SPEC_FLOOR || (env->load && !qd_fragment_is_persistent(env))) {
+    // floor contact, and the load model outside the persistent kernel (see qd_rollout): launch by launch -- controller, step, and
+    // fresh controllers for the envs that were re-sampled
+    if (!actions_out) return fail(QD_ERR_INVALID, "this PID rollout runs launch by launch and needs actions_out [T,N,4] as its action buffer");
     const size_t D = (size_t)env->D;
     for (int t = 0; t < T; t++) {
       float* a_t = actions_out + (size_t)t * k.n * 4;
@@ -1467,17 +1480,10 @@ int qd_rollout_pid(qd_env* env, int T, float* obs, float* reward, uint8_t* trunc
     QD_HIP(launch_rollout_coop(k, env->spec, T, nullptr, obs, reward, truncated, S(stream), true, actions_out));
     return QD_OK;
   }
-  const dim3 grid(blocks64(k.n)), block(64);
-#define QD_ROLL(LOADV, SPECV) QD_LAUNCH((k_rollout_pid<LOADV, SPECV>), grid, block, 0, S(stream), k, T, obs, reward, truncated, actions_out)
-  if (env->load) {
-    if (env->spec == SPEC_RMA) QD_ROLL(true, SPEC_RMA);
-    else if (env->spec == SPEC_LSTM) QD_ROLL(true, SPEC_LSTM);
-    else if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(true, SPEC_GENERIC_FS1);
-    else QD_ROLL(true, SPEC_GENERIC);
-  } else {
-    if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(false, SPEC_GENERIC_FS1);
-    else QD_ROLL(false, SPEC_GENERIC);
-  }
+  const dim3 grid(blocks64(k.n)), block(64);   // the single-body model: one wavefront per 64 envs, controller and step in one loop
+#define QD_ROLL(SPECV) QD_LAUNCH((k_rollout_pid<false, SPECV>), grid, block, 0, S(stream), k, T, obs, reward, truncated, actions_out)
+  if (env->spec == SPEC_GENERIC_FS1) QD_ROLL(SPEC_GENERIC_FS1);
+  else QD_ROLL(SPEC_GENERIC);
 #undef QD_ROLL
   QD_LAUNCH_CHECK();
   return QD_OK;

@@ -129,11 +129,7 @@ __device__ __forceinline__ void pol_issue(const float4* weights, const PolStep& 
     const float4* src = weights + lane * s.lane_mul[u];
 #pragma unroll
     for (int d = 0; d < POL_KC; d++) {
-#ifdef POL_EXP_NOLOAD
-      buf[d][u] = make_float4(0.f, 0.f, 0.f, (float)s.off[u][d] + (float)(size_t)src);  // experiment: no weight traffic
-#else
       buf[d][u] = src[s.off[u][d]];
-#endif
     }
   }
 }

@@ -622,7 +622,8 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
 }
 
 // qd_rollout_fused.hip: the closed policy -> env loop of one fragment in one launch, the env step beside the forward pass (load
-// model, SPEC_RMA rows, the feed-forward 22-value networks: arch ids 1, 2, 7, 9; hipErrorNotSupported for any other).
+// model; SPEC_RMA rows with the feed-forward 22-value networks, arch ids 1, 2, 7, 9, and SPEC_LSTM rows with CNNestimator, arch id
+// 5; hipErrorNotSupported for any other -- qd_rollout_policy then runs the two-launch loop).
 // `lds_bytes`: the policy's dynamic LDS (qd_policy_create).  `k` as qd_step would pass it.
 struct KArgs;
 hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa, size_t lds_bytes, int T, const PolSample& smp,

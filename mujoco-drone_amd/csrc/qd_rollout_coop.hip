@@ -144,13 +144,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
   const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
   const int rounds = T + (sens ? 1 : 0);
   __shared__ RcLds L;
-#ifdef RC_ROTATE
-  // experiment: the two workgroups of a CU with complementary wave -> role maps, so that no SIMD hosts two solver waves
-  const int wv = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  const int role = (((int)blockIdx.x >> RC_ROTATE) & 1) ? (wv ^ 1) : wv;
-#else
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-#endif
   const int lane = threadIdx.x & 63;
   const int base_env = blockIdx.x * 64;
   const int i = base_env + lane;
@@ -205,7 +199,7 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       const float4 action = act_next;
       if (!PID && t + 1 < T) act_next = actions4[(size_t)(t + 1) * n + il];   // in flight during this step
       const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
-      f = mass_factor<RC_PRE>(e.M, tg, a.h);
+      f = mass_factor<true>(e.M, tg, a.h);
       if (!PID && !half) rc_filter<SPEC>(a, e.M, e.s, action);   // ctrl map and activation filter: the part of the Euler step that does not wait for the accelerations
       rc_ref(a, i, e.num_steps, ref0, e.ref);
       // everything the solve reads of the factor exists BEFORE the barrier: the barrier is an asm the compiler moves pure
@@ -213,12 +207,8 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
       // path, while this wave sits at the barrier waiting for the applied wrench (stamps: phase 2 2600 cycles instead of 1800)
       rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc);
       rc_pin(f.s11, f.s12, f.s22); rc_pin(f.imt, f.m2, f.hb);
-      if constexpr (RC_PRE) {
-        rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
-        rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
-      } else {
-        rc_pin(f.S); rc_pin(f.p1); rc_pin(f.p2); rc_pin(f.d0, f.d1, f.d2); rc_pin(f.l10, f.l20, f.l21);
-      }
+      rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
+      rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
       asm volatile("" ::"v"(e.s.a0), "v"(e.s.a1), "v"(e.s.a2), "v"(e.s.a3), "v"(e.ref[0]), "v"(e.ref[1]), "v"(e.ref[2]));
       RC_STAMP(1);
       coop_barrier();   // 1
@@ -237,13 +227,13 @@ __global__ __launch_bounds__(RC_THREADS, OCC) void k_rollout_coop(KArgs a, int T
           const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
           in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
         }
-        r = reduce_rhs<RC_PRE>(f, ap, in);
+        r = reduce_rhs<true>(f, ap, in);
       }
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
       if (!half) {
         Accel<float> im;
         V3<double> a0im;
-        finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+        finish_accel<true, true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
         im.lin = mul(R, cvt<float>(a0im));
         integrate_motion<float, true>(e.s, im, a.h);
         e.flags &= ~FLAG_ACC_STALE;
@@ -643,11 +633,7 @@ hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* act
   // state of config 3 (0.45 truncations per step per 64 envs, tests/diag_persistent_big.py with QD_DIAG_WARM_STEPS=1536) 2.95 us
   // per step with the sampler against 2.62 without at 32768 envs, 91.7 against 72.8 at 2^20.  Entries are a pure function of
   // (seed, env, episode): results are the same either way, and the per-step kernels can use or ignore what is left in the arena.
-  // QD_RC_POOL_MAX_ENVS moves the limit (experiments).
-  {
-    static const int pool_max = [] { const char* e = getenv("QD_RC_POOL_MAX_ENVS"); return e ? atoi(e) : 256 * 64; }();
-    kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED && k.n <= pool_max) ? 1 : 0;
-  }
+  kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED && k.n <= 256 * 64) ? 1 : 0;
   const dim3 grid(kk.main_blocks), block(RC_THREADS);
   (void)hipGetLastError();
   const bool two = kk.main_blocks > 256;   // more workgroups than CUs: the second slot per CU is worth its register cap
@@ -657,6 +643,9 @@ hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* act
   if (!pid) {
     if (spec == SPEC_RMA) RC_LAUNCH(SPEC_RMA, 2, false);
     else if (spec == SPEC_LSTM) RC_BY_OCC(SPEC_LSTM, false);
+    // (the run-time-dispatched instantiation spills 65 registers under the two-workgroups-per-CU cap and is still the faster one
+    // where the second workgroup finds room: 8.7 against 12.0 us per step at 65536 envs, 145 against 205 at 2^20 with the
+    // spill-free OCC = 1 build, LocalFrameRmParamsEnv + reward_3, tests/diag_generic_big.py, profiles/r04_notes.md)
     else if (spec == SPEC_GENERIC_FS1) RC_BY_OCC(SPEC_GENERIC_FS1, false);
     else return hipErrorInvalidValue;
   } else {

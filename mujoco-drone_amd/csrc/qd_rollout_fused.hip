@@ -338,16 +338,12 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       // ---------------------------------------------------------- stage 1
       if (col) {
         const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
-        f = mass_factor<RC_PRE>(e.M, tg, a.h);
+        f = mass_factor<true>(e.M, tg, a.h);
         rc_ref(a, i, e.num_steps, ref0, e.ref);
         rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc);
         rc_pin(f.s11, f.s12, f.s22); rc_pin(f.imt, f.m2, f.hb);
-        if constexpr (RC_PRE) {
-          rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
-          rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
-        } else {
-          rc_pin(f.S); rc_pin(f.p1); rc_pin(f.p2); rc_pin(f.d0, f.d1, f.d2); rc_pin(f.l10, f.l20, f.l21);
-        }
+        rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
+        rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
       }
       FP_STAMP(17);
       coop_barrier();   // layer barrier 1
@@ -366,7 +362,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
             const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
             in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
           }
-          r = reduce_rhs<RC_PRE>(f, ap, in);
+          r = reduce_rhs<true>(f, ap, in);
         }
         w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
         if (sens) {   // the reading of this step (the ONLY place it is evaluated: the arena gets the same bits)
@@ -376,7 +372,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         pend = false;
         Accel<float> im;
         V3<double> a0im;
-        finish_accel<true, RC_PRE>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
+        finish_accel<true, true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
         im.lin = mul(R, cvt<float>(a0im));
         integrate_motion<float, true>(e.s, im, a.h);
         e.flags &= ~FLAG_ACC_STALE;
@@ -523,9 +519,15 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       coop_barrier();   // layer barrier 1
       // s_{t+1}, the flags and (truncated lanes) the state before the reset: as soon as wave A has published them, not a barrier later
       // (wave A never waits for this wave, so the poll ends; it is bounded all the same)
-      for (int spins = 0; spins < (1 << 20); spins++) {
-        if (*(volatile int*)&L.tag == t + 1) break;
-        __builtin_amdgcn_s_sleep(2);
+      {
+        int spins = 0;
+        for (; spins < (1 << 20); spins++) {
+          if (*(volatile int*)&L.tag == t + 1) break;
+          __builtin_amdgcn_s_sleep(2);
+        }
+        // a poll that ran out would hand wrong rows and rewards on in silence: counted instead (qd_health_counters; the tests
+        // hold the count at zero)
+        if (spins == (1 << 20) && lane == 0) health_count(a, 0);
       }
       asm volatile("" ::: "memory");
       FP_STAMP(40);
@@ -583,9 +585,21 @@ hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa
   kk.main_blocks = 0;
   const dim3 grid((k.n + POL_TILE - 1) / POL_TILE), block(FP_THREADS);
   (void)hipGetLastError();
+  // more dynamic LDS than the default limit: the instantiation opts in (160 KB per CU on gfx950), once per process and arch
 #define FP_LAUNCH(SPECV, ARCH)                                                                                                        \
-  hipLaunchKernelGGL((k_rollout_fused_pipe<SPECV, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
-                     reward, trunc, logp, logits, value)
+  do {                                                                                                                                \
+    if (lds_bytes > 64 * 1024) {                                                                                                      \
+      static size_t opted = 0;                                                                                                        \
+      if (lds_bytes > opted) {                                                                                                        \
+        const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_fused_pipe<SPECV, ARCH>),                   \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                        \
+        if (e_ != hipSuccess) return e_;                                                                                              \
+        opted = lds_bytes;                                                                                                            \
+      }                                                                                                                               \
+    }                                                                                                                                 \
+    hipLaunchKernelGGL((k_rollout_fused_pipe<SPECV, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
+                       reward, trunc, logp, logits, value);                                                                           \
+  } while (0)
   switch (arch) {
     case 1: FP_LAUNCH(SPEC_RMA, ArchRmaFull); break;
     case 2: FP_LAUNCH(SPEC_RMA, ArchRmaModel); break;

@@ -53,7 +53,8 @@ class DeviceEnv:
         self._obs_ptr, self._rew_ptr, self._trunc_ptr = self.obs.data_ptr(), self.reward.data_ptr(), self.truncated.data_ptr()
         self._dev_index = self.device.index if self.device.index is not None else torch.cuda.current_device()
         self.device = torch.device(self.device.type, self._dev_index)   # canonical form: tensors report an indexed device
-        self._frag_ok = None
+        self._frag_cache = {}
+        self._qd_step_fragment = self.lib.qd_step_fragment
         L.check(self.lib.qd_init(self.handle, self._stream()))
 
     def __del__(self):
@@ -148,24 +149,37 @@ class DeviceEnv:
     def step_fragment(self, actions, obs, reward, truncated):
         """T env steps by one C call: actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N], all caller-owned device
         tensors reused from call to call (one persistent launch, or T per-step launches replayed from a HIP graph captured on
-        first use for these buffers: qd_step_fragment)"""
+        first use for these buffers: qd_step_fragment).
+
+        The kernels write through raw pointers: a strided view, another dtype or another device would be written out of bounds or
+        as garbage, so every buffer is validated -- once per set of tensor OBJECTS.  The cache is keyed by the four objects'
+        identities and holds references to them: while an entry lives its ids cannot be handed to other tensors (a key made of
+        data_ptr()s could: the caching allocator recycles addresses, and a recycled address says nothing about dtype or strides).
+        A hit costs four id()s, a dict lookup, four data_ptr()s (an in-place set_ / resize_ of a cached tensor is caught by them)
+        and the ctypes call."""
+        ent = self._frag_cache.get((id(actions), id(obs), id(reward), id(truncated)))
+        if ent is not None:
+            ap, op, rp, tp = actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), truncated.data_ptr()
+            if (ap, op, rp, tp) == ent[1]:
+                rc = self._qd_step_fragment(self.handle, ap, ent[0], op, rp, tp, _raw_stream(self._dev_index))
+                if rc:
+                    L.check(rc)
+                return obs, reward, truncated
         T = int(actions.shape[0])
         if tuple(actions.shape[1:]) != (self.n, 4) or actions.dtype != torch.float32 or not actions.is_contiguous():
             raise ValueError("Action dimension mismatch")
         if tuple(obs.shape) != (T, self.n, self.D) or tuple(reward.shape) != (T, self.n) or tuple(truncated.shape) != (T, self.n):
             raise ValueError("fragment buffers must be [T,N,D], [T,N], [T,N]")
-        # the kernels write through these raw pointers: a strided view, another dtype or another device would be written
-        # out of bounds or as garbage.  Validated once per set of buffers (the same tensors come back every fragment).
-        key = (actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), truncated.data_ptr(), T)
-        if key != self._frag_ok:
-            for name, t, dt in (("actions", actions, torch.float32), ("obs", obs, torch.float32), ("reward", reward, torch.float32),
-                                ("truncated", truncated, torch.uint8)):
-                if t.dtype != dt or not t.is_contiguous() or t.device != self.device:
-                    raise ValueError("fragment buffer %s must be a contiguous %s tensor on %s (got %s, contiguous=%s, %s)"
-                                     % (name, dt, self.device, t.dtype, t.is_contiguous(), t.device))
-            self._frag_ok = key
-        L.check(self.lib.qd_step_fragment(self.handle, actions.data_ptr(), T, obs.data_ptr(), reward.data_ptr(), truncated.data_ptr(),
-                                          _raw_stream(self._dev_index)))
+        for name, t, dt in (("actions", actions, torch.float32), ("obs", obs, torch.float32), ("reward", reward, torch.float32),
+                            ("truncated", truncated, torch.uint8)):
+            if t.dtype != dt or not t.is_contiguous() or t.device != self.device:
+                raise ValueError("fragment buffer %s must be a contiguous %s tensor on %s (got %s, contiguous=%s, %s)"
+                                 % (name, dt, self.device, t.dtype, t.is_contiguous(), t.device))
+        ptrs = (actions.data_ptr(), obs.data_ptr(), reward.data_ptr(), truncated.data_ptr())
+        if len(self._frag_cache) >= 64:      # a sampler alternates between a few sets of buffers; a caller that never repeats one
+            self._frag_cache.clear()         # does not grow the cache (nor keep its tensors alive) without bound
+        self._frag_cache[(id(actions), id(obs), id(reward), id(truncated))] = (T, ptrs, (actions, obs, reward, truncated))
+        L.check(self._qd_step_fragment(self.handle, ptrs[0], T, ptrs[1], ptrs[2], ptrs[3], _raw_stream(self._dev_index)))
         return obs, reward, truncated
 
     def set_option(self, option, value):
@@ -184,6 +198,12 @@ class DeviceEnv:
         L.check(self.lib.qd_pool_counters(self.handle, _ptr(out), self._stream()))
         taken, inline = (int(x) & 0xFFFFFFFF for x in out.cpu().tolist())
         return taken, inline
+
+    def health_counters(self):
+        """events that must not happen since construction (qd_health_counters): (in-kernel polls that ran out,)"""
+        out = torch.zeros(1, dtype=torch.int32, device=self.device)
+        L.check(self.lib.qd_health_counters(self.handle, _ptr(out), self._stream()))
+        return tuple(int(x) & 0xFFFFFFFF for x in out.cpu().tolist())
 
     def rollout(self, actions, obs=None, reward=None, truncated=None):
         """actions [T,N,4] -> obs [T,N,D], reward [T,N], truncated [T,N] in one launch."""
@@ -218,11 +238,10 @@ class DeviceEnv:
         obs = torch.empty((T, self.n, self.D), dtype=torch.float32, **kw)
         reward = torch.empty((T, self.n), dtype=torch.float32, **kw)
         truncated = torch.empty((T, self.n), dtype=torch.uint8, **kw)
-        # floor-contact envs run the loop launch by launch and use the action buffer between controller and step
-        need_actions = want_actions or bool(self.cfg.floor_contact)
-        actions = torch.empty((T, self.n, 4), dtype=torch.float32, **kw) if need_actions else None
-        L.check(self.lib.qd_rollout_pid(self.handle, T, _ptr(obs), _ptr(reward), _ptr(truncated),
-                                        _ptr(actions) if need_actions else None, self._stream()))
+        # where the loop runs launch by launch (floor contact; the load model outside the persistent kernel) the action buffer is
+        # what carries the actions from the controller launch to the step launch: always handed over
+        actions = torch.empty((T, self.n, 4), dtype=torch.float32, **kw)
+        L.check(self.lib.qd_rollout_pid(self.handle, T, _ptr(obs), _ptr(reward), _ptr(truncated), _ptr(actions), self._stream()))
         return (obs, reward, truncated, actions) if want_actions else (obs, reward, truncated)
 
     def observe(self, out=None):

@@ -81,8 +81,9 @@ def trace_stats(d, key="k_step", grid=0, cut=0):
 
 
 def pmc(d, key="k_step", grid=0, cut=0):
-    """mean counter value per dispatch.  With --cut only the dispatches with the largest values of each counter are kept (within
-    25 % of the maximum): the counter passes carry no duration, and a persistent kernel's counters scale with its step count"""
+    """mean counter value per dispatch.  With --cut only the dispatches of the longest-launch cluster of each counter are kept (cut_mask:
+    within 1 - TOL of the typical largest value): the counter passes carry no duration, and a persistent kernel's counters scale
+    with its step count"""
     acc = defaultdict(list)
     for r in csv.DictReader(open(one(os.path.join(d, "**", "*_counter_collection.csv")))):
         if key in r["Kernel_Name"] and (not grid or int(r["Grid_Size_X"] if "Grid_Size_X" in r else r.get("Grid_Size", 0)) == grid):

@@ -227,6 +227,8 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
                 np.testing.assert_allclose(out["obs"][t].cpu().numpy(), obs.cpu().numpy(), atol=2e-5)
                 np.testing.assert_allclose(out["reward"][t].cpu().numpy(), rw.cpu().numpy(), atol=2e-5)
                 assert torch.equal(out["truncated"][t], tr)
+            # the row wave's bounded poll for the solver wave's publication never ran out (qd_health_counters)
+            assert e1._dev.health_counters() == (0,)
             assert int(out["truncated"].sum()) == 2 * 203
             q1 = [x.cpu().numpy() for x in e1._dev.get_state()]
             q2 = [x.cpu().numpy() for x in e2._dev.get_state()]
