@@ -50,6 +50,7 @@ struct CgRecord {             // one touching env, written by its own lane (floa
   double m0, c0z, I0x, I0y, I0z, m2, lc, I2t, I2a;
   // geom placement and sizes as they reach MuJoCo (%.5g), derived once by the env's own lane
   double pa, pm, arm_half, arm_thin, prop_r, rod_z, box_z, rod_half, box_half;
+  double tran[3];                           // translational body_invweight0 of core, link, tether + load (of the parameter set)
 };
 constexpr int CG_BLOCK_ENVS = 32;   // envs per workgroup of k_step_floor (four wavefronts: four passes of 8 envs run side by side)
 constexpr int CG_LANE_CONTACTS = 12;   // a lane tests at most three geoms, each yields at most four points
@@ -282,9 +283,9 @@ __device__ __forceinline__ void cg_chol_solve(const double Lc[NV * (NV + 1) / 2]
 //   cg_publish   the lane that owns a touching env describes it in G.rec[rank] (rank = its place among the workgroup's touching envs)
 //   cg_solve     a whole wavefront solves 8 of them, G.rec[base .. base + 7], one per group of 8 lanes -> G.res[base + group]
 //   cg_collect   the owning lane takes the constrained accelerations (if the floor pushes at all)
+// fc: the parameter set's floor constants (FLOOR_CONSTS planes of the arena, k_floor_consts)
 template <bool LOAD>
-__device__ __forceinline__ void cg_publish(CgRecord& r, const Model<float>& M, const State<float>& s, double arm_len, double pend_len,
-                                           double weight_mass, const Accel<float>& ex) {
+__device__ __forceinline__ void cg_publish(CgRecord& r, const Model<float>& M, const State<float>& s, const double* fc, const Accel<float>& ex) {
   TreePose P;
   const double p[3] = {(double)s.px, (double)s.py, (double)s.pz}, q[4] = {(double)s.qw, (double)s.qx, (double)s.qy, (double)s.qz};
   tree_pose(p, q, LOAD ? (double)s.th1 : 0.0, LOAD ? (double)s.th2 : 0.0, P);
@@ -296,12 +297,57 @@ __device__ __forceinline__ void cg_publish(CgRecord& r, const Model<float>& M, c
   r.a0[0] = ex.lin.x; r.a0[1] = ex.lin.y; r.a0[2] = ex.lin.z; r.a0[3] = ex.ang.x; r.a0[4] = ex.ang.y; r.a0[5] = ex.ang.z;
   r.a0[6] = ex.thdd1; r.a0[7] = ex.thdd2;
   r.m0 = M.m0; r.c0z = M.c0z; r.I0x = M.I0x; r.I0y = M.I0y; r.I0z = M.I0z; r.m2 = M.m2; r.lc = M.lc; r.I2t = M.I2t; r.I2a = M.I2a;
+  r.pa = fc[FC_PA]; r.pm = fc[FC_PM]; r.arm_half = fc[FC_ARM_HALF]; r.arm_thin = fc[FC_ARM_THIN]; r.prop_r = fc[FC_PROP_R];
+  r.rod_z = fc[FC_ROD_Z]; r.box_z = fc[FC_BOX_Z]; r.rod_half = fc[FC_ROD_HALF]; r.box_half = fc[FC_BOX_HALF];
+  r.tran[0] = fc[FC_TRAN0]; r.tran[1] = fc[FC_TRAN1]; r.tran[2] = fc[FC_TRAN2];
+}
+
+// What a parameter set fixes of the floor-contact problem, derived ONCE per parameter set (k_floor_consts) instead of in every
+// substep an env touches the floor: the geom sizes and placements as they reach MuJoCo (%.5g), the reach below the origin, and
+// the translational body_invweight0 of the three bodies -- J M^-1 J^T of each body's COM at qpos0 (identity attitude, tether straight
+// down): one 8 x 8 factorisation and nine solves (4.5 k of a substep's 98 k cycles; the nine roundings another ~5 k).
+template <bool LOAD>
+__device__ __forceinline__ void cg_floor_consts(const Model<float>& M, double arm_len, double pend_len, double weight_mass, double fc[13]) {
+  constexpr int NV = LOAD ? 8 : 6, NT = NV * (NV + 1) / 2;
   const double sq2 = 1.4142135623730951, cs45 = 0.70710678118654752440;
-  r.pa = cg_round5((sq2 * 0.05 + 0.5 * arm_len) * cs45);
-  r.pm = cg_round5((sq2 * 0.05 + arm_len) * cs45);
-  r.arm_half = cg_round5(arm_len / 2); r.arm_thin = cg_round5(arm_len / 20); r.prop_r = cg_round5(arm_len / 1.5);
-  r.rod_z = LOAD ? cg_round5(-pend_len / 2) : 0.0; r.box_z = LOAD ? cg_round5(-pend_len) : 0.0;
-  r.rod_half = LOAD ? cg_round5(pend_len / 2) : 0.0; r.box_half = LOAD ? cg_round5(0.1 * cbrt(weight_mass)) : 0.0;
+  fc[FC_PA] = cg_round5((sq2 * 0.05 + 0.5 * arm_len) * cs45);
+  fc[FC_PM] = cg_round5((sq2 * 0.05 + arm_len) * cs45);
+  fc[FC_ARM_HALF] = cg_round5(arm_len / 2); fc[FC_ARM_THIN] = cg_round5(arm_len / 20); fc[FC_PROP_R] = cg_round5(arm_len / 1.5);
+  fc[FC_ROD_Z] = LOAD ? cg_round5(-pend_len / 2) : 0.0; fc[FC_BOX_Z] = LOAD ? cg_round5(-pend_len) : 0.0;
+  fc[FC_ROD_HALF] = LOAD ? cg_round5(pend_len / 2) : 0.0; fc[FC_BOX_HALF] = LOAD ? cg_round5(0.1 * cbrt(weight_mass)) : 0.0;
+  // nothing of the drone reaches further than this below its origin (qd_contact.h: floor_contact / floor_contact_tree)
+  double reach = 1.4142135623730951 * 0.05 + arm_len * (1.0 + 1.0 / 1.5) + 0.03;
+  if (LOAD) reach += pend_len + 1.7320508075688772 * fc[FC_BOX_HALF];
+  fc[FC_REACH] = reach;
+  fc[FC_TRAN0] = 1.0 / (double)M.m0; fc[FC_TRAN1] = 0.0; fc[FC_TRAN2] = 0.0;
+  if constexpr (LOAD) {
+    CgRecord r;
+    r.m0 = M.m0; r.c0z = M.c0z; r.I0x = M.I0x; r.I0y = M.I0y; r.I0z = M.I0z; r.m2 = M.m2; r.lc = M.lc; r.I2t = M.I2t; r.I2a = M.I2a;
+    const double z3[3] = {0, 0, 0}, I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xa0[3] = {0, 0, Const::anchor_z};
+    double L0[NT];
+    cg_mass_matrix<NV>(r, z3, I9, I9, I9, xa0, L0);
+    cg_chol<NV>(L0);
+    double part[3] = {0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int q9 = 0; q9 < 9; q9++) {
+      const int b = q9 / 3, k = q9 - 3 * b;
+      const double z = b == 0 ? r.c0z : (b == 1 ? Const::anchor_z : Const::anchor_z - r.lc), za = z - Const::anchor_z;
+      double Jr[NV], xs[NV];
+#pragma unroll
+      for (int j = 0; j < NV; j++) Jr[j] = (j == k) ? 1.0 : 0.0;
+      // (e_j x r)_k with r = (0, 0, z): e_x x r = (0, -z, 0), e_y x r = (z, 0, 0), e_z x r = 0
+      if (k == 1) Jr[3] = -z;
+      if (k == 0) Jr[4] = z;
+      if (b >= 1 && k == 1) Jr[6] = -za;   // hinge x, from the anchor
+      if (b == 2 && k == 0) Jr[7] = za;    // hinge y
+      cg_chol_solve<NV>(L0, Jr, xs);
+      double t = 0.0;
+#pragma unroll
+      for (int j = 0; j < NV; j++) t += Jr[j] * xs[j];
+      part[b] += t;
+    }
+    fc[FC_TRAN0] = part[0] / 3.0; fc[FC_TRAN1] = part[1] / 3.0; fc[FC_TRAN2] = part[2] / 3.0;
+  }
 }
 
 template <bool LOAD>
@@ -354,35 +400,7 @@ __device__ __forceinline__ void cg_solve(CgLds& G, CgWave& W, int base, int tota
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       const double* Mm = W.mm[grp];
       if (threadIdx.x < 64) SF_STAMP(9);
-      double tran[3] = {1.0 / r.m0, 0.0, 0.0};
-      if constexpr (LOAD) {
-        // J M^-1 J^T of each body's COM at qpos0 (identity attitude, tether straight down): one factorisation, nine solves
-        const double z3[3] = {0, 0, 0}, I9[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1}, xa0[3] = {0, 0, Const::anchor_z};
-        double L0[NT];
-        cg_mass_matrix<NV>(r, z3, I9, I9, I9, xa0, L0);
-        cg_chol<NV>(L0);
-        // at qpos0 the COM Jacobians are: rows e_k plus (axis_j x r) columns with r along z only.  The nine solves (3 bodies x
-        // 3 rows) are dealt to the 8 lanes (lane 0 takes two) and summed per body over the group
-        double part0 = 0.0, part1 = 0.0, part2 = 0.0;
-        for (int q9 = sub; q9 < 9; q9 += 8) {
-          const int b = q9 / 3, k = q9 - 3 * b;
-          const double z = b == 0 ? r.c0z : (b == 1 ? Const::anchor_z : Const::anchor_z - r.lc), za = z - Const::anchor_z;
-          double Jr[NV], xs[NV];
-#pragma unroll
-          for (int j = 0; j < NV; j++) Jr[j] = (j == k) ? 1.0 : 0.0;
-          // (e_j x r)_k with r = (0, 0, z): e_x x r = (0, -z, 0), e_y x r = (z, 0, 0), e_z x r = 0
-          if (k == 1) Jr[3] = -z;
-          if (k == 0) Jr[4] = z;
-          if (b >= 1 && k == 1) Jr[6] = -za;   // hinge x, from the anchor
-          if (b == 2 && k == 0) Jr[7] = za;    // hinge y
-          cg_chol_solve<NV>(L0, Jr, xs);
-          double t = 0.0;
-#pragma unroll
-          for (int j = 0; j < NV; j++) t += Jr[j] * xs[j];
-          if (b == 0) part0 += t; else if (b == 1) part1 += t; else part2 += t;
-        }
-        tran[0] = cg_sum8(part0) / 3.0; tran[1] = cg_sum8(part1) / 3.0; tran[2] = cg_sum8(part2) / 3.0;
-      }
+      const double tran[3] = {r.tran[0], r.tran[1], r.tran[2]};   // body_invweight0: a function of the parameter set (cg_floor_consts)
       if (threadIdx.x < 64) SF_STAMP(10);
       const double mu = 1.0, tc = h * 2.0 > 0.02 ? h * 2.0 : 0.02, dmax = 0.95;
       const double kb = 2.0 / (dmax * tc), kk = 1.0 / (dmax * dmax * tc * tc);

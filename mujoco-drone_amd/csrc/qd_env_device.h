@@ -28,7 +28,11 @@ enum Group {
   G_C0, G_C1, G_C2, G_C3,             // memory of the analytic PID cascade (qd_pid.h); touched only by the qd_pid_* entry points
   NUM_GROUPS
 };
-constexpr int RAW_PLANES = 6;
+// float64 planes behind the float4 groups: the six raw parameters (the 5-digit XML rounding must see float64 values), then what the
+// floor-contact step needs of a parameter set and used to re-derive in every substep: the nine %.5g-rounded geom sizes /
+// placements, the reach below the origin, the translational body_invweight0 of the three bodies (k_floor_consts, qd_step_floor.hip)
+constexpr int RAW_PARAMS = 6;
+constexpr int RAW_PLANES = RAW_PARAMS + FLOOR_CONSTS;   // FLOOR_CONSTS and its indices: qd_model.h
 constexpr int POOL_STAT_WORDS = 64;   // behind the refill counters: [0] in-kernel resets served by the pool, [1] sampled inline (qd_pool_counters);
                                       // [8 + k]: events that must not happen (qd_health_counters): k = 0 a bounded in-kernel poll ran out
 constexpr int PAD = 256;
@@ -659,7 +663,9 @@ hipError_t launch_rollout_coop(const KArgs& k, int spec, int T, const float* act
 hipError_t launch_rollout_lat(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 // SimpleDrone's fragments at small batches: a physics wave and an epilogue wave per 64 envs (qd_rollout_coop.hip)
 hipError_t launch_rollout_pair(const KArgs& k, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
-// qd_step_floor.hip: one env step of a floor-contact configuration (SPEC_FLOOR), any batch size
+// qd_step_floor.hip: the floor-contact constants of the current parameter set (after every k_params of a floor-contact env), and
+// one env step of a floor-contact configuration (SPEC_FLOOR), any batch size
+hipError_t launch_floor_consts(const KArgs& k, bool load, hipStream_t stream);
 hipError_t launch_step_floor(const KArgs& k, bool load, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream);
 
 }  // namespace qd

@@ -1055,6 +1055,7 @@ int qd_init(qd_env* env, void* stream) {
   QD_LAUNCH_CHECK();
   QD_LAUNCH(k_params, dim3(blocks64(k.n)), dim3(64), 0, S(stream), k, env->pc, env->regen, (const double*)nullptr, 1);
   QD_LAUNCH_CHECK();
+  if (env->spec == SPEC_FLOOR) QD_HIP(launch_floor_consts(k, env->load, S(stream)));
   return QD_OK;
 }
 
@@ -1095,6 +1096,7 @@ int qd_randomize_params(qd_env* env, void* stream) {
   QD_LAUNCH(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen,
                      (const double*)nullptr, 1);
   QD_LAUNCH_CHECK();
+  if (env->spec == SPEC_FLOOR) QD_HIP(launch_floor_consts(env->ka, env->load, S(stream)));
   return QD_OK;
 }
 
@@ -1103,6 +1105,7 @@ int qd_set_params(qd_env* env, const double* raw, void* stream) {
   if (!raw) return fail(QD_ERR_INVALID, "null params");
   QD_LAUNCH(k_params, dim3(blocks64(env->ka.n)), dim3(64), 0, S(stream), env->ka, env->pc, env->regen, raw, 0);
   QD_LAUNCH_CHECK();
+  if (env->spec == SPEC_FLOOR) QD_HIP(launch_floor_consts(env->ka, env->load, S(stream)));
   return QD_OK;
 }
 

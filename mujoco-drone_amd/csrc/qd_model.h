@@ -53,6 +53,11 @@ struct Model {
 // M0..M2 (+ I2a) determine everything else: fluid_coeffs_inline() re-folds planes M3..M6 from them
 constexpr int MODEL_FLOATS = 28;
 
+// what a parameter set fixes of the floor-contact problem (qd_contact_group.h: cg_floor_consts; one float64 plane each in the arena):
+// geom placements and sizes as they reach MuJoCo, the reach below the origin, translational body_invweight0 of the three bodies
+constexpr int FLOOR_CONSTS = 13;
+enum { FC_PA = 0, FC_PM, FC_ARM_HALF, FC_ARM_THIN, FC_PROP_R, FC_ROD_Z, FC_BOX_Z, FC_ROD_HALF, FC_BOX_HALF, FC_REACH, FC_TRAN0, FC_TRAN1, FC_TRAN2 };
+
 // link sphere (env_gen.py:68): its inertia box is a cube of side r*sqrt(2.4)
 struct LinkFluid {
   static constexpr double b = 0.02 * 1.5491933384829668;

@@ -23,7 +23,7 @@ struct SfOwn {
   Accel<float> ex, im;
   V3<float> acc, lin0, ang0;
   float c0, c1, c2, c3;
-  double arm_len, pend_len, weight_mass, reach;
+  double fc[FLOOR_CONSTS];   // the parameter set's floor constants (arena planes behind the raw parameters)
 };
 
 template <bool LOAD>
@@ -51,13 +51,9 @@ __global__ __launch_bounds__(SF_THREADS) void k_step_floor(KArgs a, const float*
     float c0 = action.x, c1 = action.y, c2 = action.z, c3 = action.w;
     if (a.ctrl_map == QD_CTRL_AFFINE) { c0 = 0.1f + 0.9f * c0; c1 = 0.1f + 0.9f * c1; c2 = 0.1f + 0.9f * c2; c3 = 0.1f + 0.9f * c3; }
     o.c0 = qclamp(c0, 0.f, 1.f); o.c1 = qclamp(c1, 0.f, 1.f); o.c2 = qclamp(c2, 0.f, 1.f); o.c3 = qclamp(c3, 0.f, 1.f);
-    // float64 raw parameter planes: the geom sizes are %.5g-rounded from them
-    o.arm_len = a.raw[(size_t)1 * a.npad + il];
-    o.pend_len = LOAD ? a.raw[(size_t)4 * a.npad + il] : 0.0;
-    o.weight_mass = LOAD ? a.raw[(size_t)5 * a.npad + il] : 0.0;
-    // nothing of the drone reaches further than this below its origin (qd_contact.h: floor_contact / floor_contact_tree)
-    o.reach = 1.4142135623730951 * 0.05 + o.arm_len * (1.0 + 1.0 / 1.5) + 0.03;
-    if (LOAD) o.reach += o.pend_len + 1.7320508075688772 * cg_round5(0.1 * cbrt(o.weight_mass));
+    // sizes, reach and body_invweight0 of this parameter set: derived once per parameter set by k_floor_consts
+#pragma unroll
+    for (int k = 0; k < FLOOR_CONSTS; k++) o.fc[k] = a.raw[(size_t)(RAW_PARAMS + k) * a.npad + il];
   }
   for (int k = 0; k < a.frame_skip; k++) {
     bool touch = false;
@@ -67,14 +63,14 @@ __global__ __launch_bounds__(SF_THREADS) void k_step_floor(KArgs a, const float*
       if (owner) {
         forward<float, LOAD>(o.e.M, o.e.s, a.h, &o.ex, &o.im, &o.acc);
         o.lin0 = o.ex.lin; o.ang0 = o.ex.ang;
-        touch = live && !((double)o.e.s.pz > o.reach);
+        touch = live && !((double)o.e.s.pz > o.fc[FC_REACH]);
       }
       SF_STAMP(1);
       const unsigned long long mask = __ballot(touch ? 1 : 0);
       rank = __popcll(mask & ((1ull << lane) - 1ull));
       if (lane == 0) n_touch = __popcll(mask);
       if (mask != 0ull) {   // (wave-uniform) somebody can reach the floor: describe those envs, park everybody's registers
-        if (touch) cg_publish<LOAD>(G.rec[rank], o.e.M, o.e.s, o.arm_len, o.pend_len, o.weight_mass, o.ex);
+        if (touch) cg_publish<LOAD>(G.rec[rank], o.e.M, o.e.s, o.fc, o.ex);
         if (owner) park[lane] = o;
       }
       SF_STAMP(2);
@@ -146,6 +142,27 @@ __global__ __launch_bounds__(SF_THREADS) void k_step_floor(KArgs a, const float*
   }
   __builtin_amdgcn_wave_barrier();
   if (base_env < a.n) flush_obs(tile, obs + (size_t)base_env * a.D, min(CG_BLOCK_ENVS, a.n - base_env), a.D);
+}
+
+// the floor constants of every env's current parameter set, into the arena planes behind the raw parameters
+template <bool LOAD>
+__global__ __launch_bounds__(64) void k_floor_consts(KArgs a) {
+  const int i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= a.n) return;
+  EnvRegs e;
+  load_env_planes<LOAD, false, false>(a.g, a.npad, i, e);
+  double fc[FLOOR_CONSTS];
+  cg_floor_consts<LOAD>(e.M, a.raw[(size_t)1 * a.npad + i], LOAD ? a.raw[(size_t)4 * a.npad + i] : 0.0, LOAD ? a.raw[(size_t)5 * a.npad + i] : 0.0, fc);
+#pragma unroll
+  for (int k = 0; k < FLOOR_CONSTS; k++) a.raw[(size_t)(RAW_PARAMS + k) * a.npad + i] = fc[k];
+}
+
+hipError_t launch_floor_consts(const KArgs& k, bool load, hipStream_t stream) {
+  const dim3 grid((k.n + 63) / 64), block(64);
+  (void)hipGetLastError();
+  if (load) hipLaunchKernelGGL((k_floor_consts<true>), grid, block, 0, stream, k);
+  else hipLaunchKernelGGL((k_floor_consts<false>), grid, block, 0, stream, k);
+  return hipGetLastError();
 }
 
 hipError_t launch_step_floor(const KArgs& k, bool load, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {

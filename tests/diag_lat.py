@@ -75,4 +75,9 @@ else:
         for w, wn in ((1, "B"), (3, "D")):
             d = acc[:, w, 3] - acc[:, w, 2]
             print("  wave %s phase 2: median %5.0f p10 %5.0f p90 %5.0f mean %5.0f" % (wn, np.median(d), np.percentile(d, 10), np.percentile(d, 90), d.mean()))
+        d = acc[:, 3, :]
+        if d[:, 7].max() > 0:
+            for nm, lo, hi in (("step start -> state in registers", 0, 8), ("-> phase 1 done", 8, 1), ("barrier 1 -> reward stored", 2, 7), ("-> rows stored (phase 2 done)", 7, 3)):
+                x = d[:, hi] - d[:, lo]
+                print("  wave D %-42s median %5.0f  p10 %5.0f  p90 %5.0f" % (nm, np.median(x), np.percentile(x, 10), np.percentile(x, 90)))
         print("  step period mean %.0f" % per.mean())

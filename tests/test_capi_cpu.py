@@ -58,8 +58,8 @@ def test_dimensions(L):
     assert lib.qd_obs_dim(L.OBS_KINDS.index("BaseDroneEnv"), L.MODEL_NOLOAD) == 29
     assert lib.qd_obs_dim(99, 1) == -1
     assert lib.qd_arena_bytes(0) == 0
-    assert lib.qd_arena_bytes(4096) == 4096 * (39 * 16 + 6 * 8) + (4096 // 64 + 64) * 4   # planes + one refill counter per 64 envs + 64 words of pool statistics
-    assert lib.qd_arena_bytes(4097) == 4352 * (39 * 16 + 6 * 8) + (4352 // 64 + 64) * 4   # padded to 256 envs
+    assert lib.qd_arena_bytes(4096) == 4096 * (39 * 16 + 19 * 8) + (4096 // 64 + 64) * 4   # float4 planes + float64 planes (6 raw parameters, 13 floor constants) + one refill counter per 64 envs + 64 words of statistics
+    assert lib.qd_arena_bytes(4097) == 4352 * (39 * 16 + 19 * 8) + (4352 // 64 + 64) * 4   # padded to 256 envs
 
 
 def _cfg(L, **kw):
