@@ -481,21 +481,65 @@ QD_HD Inv5<HP> mass_inverse(const LatConsts<HP>& k, const TetherHP<HP>& th) {
   v.kp2 = mk<HP>(k.kl * (c1 * dz - s1 * dy), k.kl * (s1 * dx), -k.kl * (c1 * dx));  // kl (y2 x d)
   return v;
 }
-// the damping-implicit generalised accelerations from the two wrenches (what reduce_rhs + finish_accel<true> give)
+// the damping-implicit generalised accelerations from the two wrenches (what reduce_rhs + finish_accel<true> give), in two stages: the
+// angular and hinge accelerations (kept in HP: explicit_from_implicit() below starts from them), then the origin's
+template <class HP>
+struct Rot5 {
+  V3<HP> fl, al;
+  HP t1, t2;
+};
+template <class T, class HP>
+QD_HD Rot5<HP> solve_inv5_rot(const Inv5<HP>& v, const Applied<T>& ap, const Inertial<HP>& in) {
+  Rot5<HP> r;
+  r.fl = cvt<HP>(ap.F) - in.F;
+  const V3<HP> fw = cvt<HP>(ap.Tq) - in.Tq;
+  const HP ft1 = HP(ap.t1) - in.t1, ft2 = HP(ap.t2) - in.t2;
+  const V3<HP> fwr = fw - cross(v.rc, r.fl);
+  const HP g1 = ft1 - (v.kp1.y * r.fl.y + v.kp1.z * r.fl.z), g2 = ft2 - dot(v.kp2, r.fl);
+  r.al = mk<HP>(v.cxx * fwr.x + v.cxy * fwr.y + v.cxz * fwr.z - g1 * v.U1.x - g2 * v.U2.x,
+                v.cxy * fwr.x + v.cyy * fwr.y + v.cyz * fwr.z - g1 * v.U1.y - g2 * v.U2.y,
+                v.cxz * fwr.x + v.cyz * fwr.y + v.czz * fwr.z - g1 * v.U1.z - g2 * v.U2.z);
+  r.t1 = v.s11 * g1 + v.s12 * g2 - dot(v.U1, fwr);
+  r.t2 = v.s12 * g1 + v.s22 * g2 - dot(v.U2, fwr);
+  return r;
+}
+template <class HP>
+QD_HD V3<HP> solve_inv5_lin(const LatConsts<HP>& k, const Inv5<HP>& v, const Rot5<HP>& r) {
+  return k.imt * r.fl - cross(r.al, v.rc) - r.t1 * v.kp1 - r.t2 * v.kp2;
+}
 template <class T, class HP>
 QD_HD void solve_inv5(const LatConsts<HP>& k, const Inv5<HP>& v, const Applied<T>& ap, const Inertial<HP>& in, V3<HP>* a0, V3<T>* ang, T* thdd1,
                       T* thdd2) {
-  const V3<HP> fl = cvt<HP>(ap.F) - in.F;
-  const V3<HP> fw = cvt<HP>(ap.Tq) - in.Tq;
-  const HP ft1 = HP(ap.t1) - in.t1, ft2 = HP(ap.t2) - in.t2;
-  const V3<HP> fwr = fw - cross(v.rc, fl);
-  const HP g1 = ft1 - (v.kp1.y * fl.y + v.kp1.z * fl.z), g2 = ft2 - dot(v.kp2, fl);
-  const V3<HP> al = mk<HP>(v.cxx * fwr.x + v.cxy * fwr.y + v.cxz * fwr.z - g1 * v.U1.x - g2 * v.U2.x,
-                           v.cxy * fwr.x + v.cyy * fwr.y + v.cyz * fwr.z - g1 * v.U1.y - g2 * v.U2.y,
-                           v.cxz * fwr.x + v.cyz * fwr.y + v.czz * fwr.z - g1 * v.U1.z - g2 * v.U2.z);
-  const HP t1 = v.s11 * g1 + v.s12 * g2 - dot(v.U1, fwr), t2 = v.s12 * g1 + v.s22 * g2 - dot(v.U2, fwr);
-  *a0 = k.imt * fl - cross(al, v.rc) - t1 * v.kp1 - t2 * v.kp2;
-  *ang = cvt<T>(al); *thdd1 = T(t1); *thdd2 = T(t2);
+  const Rot5<HP> r = solve_inv5_rot(v, ap, in);
+  *a0 = solve_inv5_lin(k, v, r);
+  *ang = cvt<T>(r.al); *thdd1 = T(r.t1); *thdd2 = T(r.t2);
+}
+
+// The damping-EXPLICIT accelerations (what MuJoCo stores in qacc and the accelerometer reads) from the implicit solve, without a second
+// inverse: the two systems differ by h b on the two hinge diagonals, A_ex = A_im - h b E E^T, so by Woodbury
+//     x_ex = x_im + G E W E^T x_im,    W = (1 / (h b) - E^T G E)^-1 = (1 / (h b) - [s11 s12; s12 s22])^-1    (2 x 2),
+// with G E = the inverse's two hinge columns (-U1, -U2 | s): four multiply-adds for W (t1, t2), ten for the correction.
+template <class HP>
+struct ExW {
+  HP w11, w12, w22;
+};
+template <class HP>
+QD_HD ExW<HP> explicit_weights(const LatConsts<HP>& k, const Inv5<HP>& v) {
+  const HP ih = HP(1) / k.hb;
+  const HP a = ih - v.s11, d = ih - v.s22, b = -v.s12;
+  const HP idet = frcp(a * d - b * b);
+  ExW<HP> w;
+  w.w11 = d * idet; w.w22 = a * idet; w.w12 = -b * idet;
+  return w;
+}
+template <class T, class HP>
+QD_HD void explicit_from_implicit(const LatConsts<HP>& k, const Inv5<HP>& v, const ExW<HP>& w, V3<HP> fl, V3<HP> al, HP t1, HP t2, V3<HP>* a0ex,
+                                  V3<T>* ang, T* thdd1, T* thdd2) {
+  const HP d1 = w.w11 * t1 + w.w12 * t2, d2 = w.w12 * t1 + w.w22 * t2;
+  const V3<HP> ale = al - d1 * v.U1 - d2 * v.U2;
+  const HP t1e = t1 + v.s11 * d1 + v.s12 * d2, t2e = t2 + v.s12 * d1 + v.s22 * d2;
+  *a0ex = k.imt * fl - cross(ale, v.rc) - t1e * v.kp1 - t2e * v.kp2;
+  *ang = cvt<T>(ale); *thdd1 = T(t1e); *thdd2 = T(t2e);
 }
 
 // applied_wrench() in two halves, for two wavefronts: rotors + drag on core and link | drag on the tether.  Their sum is the
@@ -561,7 +605,7 @@ QD_HD void attitude_min(const State<T>& s, M3<T>* R, V3<T>* vb) {
 
 // The same forward dynamics composed from the latency pieces in one lane (implicit accelerations only; host twin test).
 template <class T>
-QD_HD void forward_lat(const Model<T>& M, const State<T>& s, T h, Accel<T>* im) {
+QD_HD void forward_lat(const Model<T>& M, const State<T>& s, T h, Accel<T>* im, Accel<T>* ex = nullptr, V3<T>* acc = nullptr) {
   using HP = typename HighPrec<T>::type;
   M3<T> R;
   V3<T> vb;
@@ -581,6 +625,19 @@ QD_HD void forward_lat(const Model<T>& M, const State<T>& s, T h, Accel<T>* im) 
   V3<HP> a0;
   solve_inv5(k, v, ap, in, &a0, &im->ang, &im->thdd1, &im->thdd2);
   im->lin = mul(R, cvt<T>(a0));
+  if (ex) {
+    const Rot5<HP> r5 = solve_inv5_rot(v, ap, in);   // (the implicit solution once more, in HP)
+    const V3<HP> fl = r5.fl, al = r5.al;
+    const HP t1 = r5.t1, t2 = r5.t2;
+    V3<HP> a0ex;
+    explicit_from_implicit(k, v, explicit_weights(k, v), fl, al, t1, t2, &a0ex, &ex->ang, &ex->thdd1, &ex->thdd2);
+    const V3<T> a0e = cvt<T>(a0ex);
+    ex->lin = mul(R, a0e);
+    if (acc) {
+      const T g = T(Const::gravity);
+      *acc = accelerometer(a0e, ex->ang, mk<T>(g * R.m20, g * R.m21, g * R.m22), mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y)));
+    }
+  }
 }
 
 // The accelerometer reading as an affine function of the activations at a fixed state: reading(a) = c0 + sum_i a_i col_i.

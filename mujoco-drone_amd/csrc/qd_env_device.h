@@ -632,6 +632,16 @@ __device__ __forceinline__ void rc_filter(const KArgs& a, const Model<float>& M,
   integrate_act(M, s, qclamp(c0, 0.f, 1.f), qclamp(c1, 0.f, 1.f), qclamp(c2, 0.f, 1.f), qclamp(c3, 0.f, 1.f), a.h);
 }
 
+// where the three accelerometer values sit in the observation row of a variant that carries them (-1: it does not)
+__device__ __forceinline__ int rc_acc_slot(int kind) {
+  switch (kind) {
+    case OBS_RAW: return 16;
+    case OBS_FULLSTATE: case OBS_PRY_ACC: case OBS_PRY_ACC_NOPEND: return 12;
+    case OBS_FULLSTATE_ZVEC: return 13;
+    case OBS_PRY_ACC_PARAMS: return 14;
+    default: return -1;
+  }
+}
 // the env's reference at episode step k (static: `base`, fetched once)
 __device__ __forceinline__ void rc_ref(const KArgs& a, int i, int k, const float base[4], float ref[4]) {
   if (a.ref_mode != QD_REF_STATIC) moving_reference(a, i, k, ref);

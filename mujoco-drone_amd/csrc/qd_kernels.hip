@@ -1243,7 +1243,7 @@ static bool qd_fragment_is_persistent(const qd_env* env) {
 static bool qd_fragment_is_latency(const qd_env* env) {
   if (!qd_fragment_is_persistent(env) || !env->opt[QD_OPT_LATENCY_KERNEL]) return false;
   if (env->ka.n > 256 * 64) return false;
-  return env->spec == SPEC_RMA || (env->spec == SPEC_GENERIC_FS1 && !env->ka.obs_needs_acc);
+  return env->spec == SPEC_RMA || env->spec == SPEC_LSTM || env->spec == SPEC_GENERIC_FS1;
 }
 // The single-body model (SimpleDrone, and BaseDroneEnv without the load): its step is ~500 float32 instructions, too short to be
 // worth a split over waves, so a fragment runs in k_rollout -- one wavefront per 64 envs, state in registers, rows through the
@@ -1288,7 +1288,7 @@ const char* qd_fragment_kernel_name(const qd_env* env) {
     return buf;
   }
   if (!qd_fragment_is_persistent(env)) return qd_step_kernel_name(env);
-  if (qd_fragment_is_latency(env)) return env->spec == SPEC_RMA ? "qd::k_rollout_lat<1>" : "qd::k_rollout_lat<4>";
+  if (qd_fragment_is_latency(env)) return env->spec == SPEC_RMA ? "qd::k_rollout_lat<1>" : env->spec == SPEC_LSTM ? "qd::k_rollout_lat<2>" : "qd::k_rollout_lat<4>";
   const bool two = env->ka.n > 256 * 64;
   return env->spec == SPEC_RMA ? "qd::k_rollout_coop<1,2>"
        : env->spec == SPEC_LSTM ? (two ? "qd::k_rollout_coop<2,2>" : "qd::k_rollout_coop<2,1>")

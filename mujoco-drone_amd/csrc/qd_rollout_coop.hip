@@ -103,16 +103,6 @@ __device__ unsigned long long qd_rcstamps[64 * 4 * 16];
 #define RC_STAMP(k)
 #endif
 
-// where the three accelerometer values sit in the observation row of a variant that carries them (-1: it does not)
-__device__ __forceinline__ int rc_acc_slot(int kind) {
-  switch (kind) {
-    case OBS_RAW: return 16;
-    case OBS_FULLSTATE: case OBS_PRY_ACC: case OBS_PRY_ACC_NOPEND: return 12;
-    case OBS_FULLSTATE_ZVEC: return 13;
-    case OBS_PRY_ACC_PARAMS: return 14;
-    default: return -1;
-  }
-}
 // SPEC_RMA (train_PPO.py / train_RMA.py), SPEC_LSTM (train_LSTM.py) or SPEC_GENERIC_FS1 (any observation / reward of the load
 // model, dispatched at run time in wave D), all with skip_steps = 1.
 //

@@ -29,9 +29,6 @@
 namespace qd {
 
 constexpr int RL_THREADS = 256;
-#ifndef RL_REWARD_IN_D
-#define RL_REWARD_IN_D 1   // the reward of step t - 1 in wave D's phase 2 (own state vector) instead of behind wave B's row
-#endif
 
 // The state as wave A publishes it, grouped by WHEN a value is final inside the solver's phase 2, so that the LDS writes leave while
 // the rest of the integration still runs (a block of six writes behind the last value cost ~170 cycles of drain in front of barrier 2):
@@ -46,6 +43,7 @@ struct RlLds {
   double2 ine[4][64];         // C -> A: Inertial (F, Tq, t1, t2) of link and tether
   float4 st[RL_PLANES][64];   // A -> B, C, D: the state AFTER the step, before any reset (the reward of a truncated lane is of this state)
   uint4 info[64];             // A -> B, C, D: (bit 0 truncated | bit 1 reset), episode counter of s_{t+1}, num_steps after the step, -
+  float4 accv[64];            // A -> B, D (sensor-reading rows): the accelerometer reading of the step solved in the last phase 2
   // The reset pool: slot e & 1 = entry of episode e, in the planes of `st` plus the tag plane.  A lane that is reset takes its new state
   // from here -- EVERY wave for itself, at the start of the next phase 1 (rl_get_start): the entry is in LDS already, so a reset costs the
   // solver wave no write at all (writing the pre-reset and the new state out for the other waves: +740 cycles on its critical phase in
@@ -165,8 +163,17 @@ __device__ unsigned long long qd_rlstamps[64 * 4 * 16];
 template <int SPEC>
 __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, const float* __restrict__ actions, float* __restrict__ obs,
                                                                float* __restrict__ reward_out, uint8_t* __restrict__ trunc_out) {
-  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_GENERIC_FS1, "latency-bound fragment kernel: the load model, one substep per step");
+  static_assert(SPEC == SPEC_RMA || SPEC == SPEC_LSTM || SPEC == SPEC_GENERIC_FS1, "latency-bound fragment kernel: the load model, one substep per step");
   const int D = spec_runtime<SPEC>() ? a.D : spec_obs_dim<SPEC>();
+  // Observation variants that carry the accelerometer (`sens`: train_LSTM.py's LocalFrameFullStateEnv, BaseDroneEnv's raw row, the
+  // ...acc... wrappers).  The reading in the row of step k is the one mj_step computed in that step at the state it STARTED from
+  // (quirk C-6): the damping-explicit accelerations of round k's solve, which the solver wave gets from its implicit solution by a
+  // 2 x 2 correction (explicit_from_implicit) and publishes in L.accv.  The row of a lane that was reset in step k instead carries
+  // mj_forward's reading at the NEW state with the activations that survived (set_state -> mj_forward, mujoco_vecenv.py:396-402):
+  // round k + 1's reading -- the row wave leaves those three entries open and the store wave fills them in a round later, before
+  // the row goes out.  The fragment's last row needs the reading at s_T: one extra half round (wrenches and solve, nothing integrated).
+  const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
+  const int acc_at = sens ? rc_acc_slot(spec_obs<SPEC>(a)) : -1;
   __shared__ RlLds L;
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -206,8 +213,10 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
     R.m00 = R.m11 = R.m22 = 1.f; R.m01 = R.m02 = R.m10 = R.m12 = R.m20 = R.m21 = 0.f;
     V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
     float th1_last = e.s.th1, th2_last = e.s.th2;
-    for (int t = 0; t < T; t++) {
+    V3<float> acc_step = mk<float>(0.f, 0.f, 0.f), acc_before = mk<float>(0.f, 0.f, 0.f);   // the readings of the last two solves
+    for (int t = 0; t < T + (sens ? 1 : 0); t++) {
       RL_STAMP(0);
+      const bool half = t == T;   // `sens` only: the forward dynamics at s_T, nothing integrated
       // ---------------------------------------------------------- phase 1
       rl_take_reset<true, true>(L, lane, mark_prev, e.s);   // this wave reset the lane a phase ago: the new episode's state
       th1_last = e.s.th1; th2_last = e.s.th2;
@@ -239,15 +248,31 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         ap.Tq = mk<float>(b1.x + d1.x, b1.y + d1.y, b1.z + d1.z); ap.t2 = d1.w;
         in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
       }
-      ap_last = ap; in_last = in;
+      if (!half) { ap_last = ap; in_last = in; }
       w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
       const float h = a.h;
+      const Rot5<double> r5 = solve_inv5_rot(v5, ap, in);
+      if (sens) {   // the accelerometer reading of this solve: explicit accelerations by the 2 x 2 correction of the implicit ones
+        V3<double> a0ex;
+        V3<float> angex;
+        float d1, d2;
+        explicit_from_implicit(K, v5, explicit_weights(K, v5), r5.fl, r5.al, r5.t1, r5.t2, &a0ex, &angex, &d1, &d2);
+        const float g = float(Const::gravity);
+        acc_before = acc_step;
+        acc_step = accelerometer(cvt<float>(a0ex), angex, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                                 mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+        L.accv[lane] = make_float4(acc_step.x, acc_step.y, acc_step.z, 0.f);
+      }
+      if (half) {
+        RL_STAMP(3);
+        coop_barrier();   // 2 (of the half round: the reading at s_T is published)
+        RL_STAMP(4);
+        break;
+      }
       {
-        V3<double> a0im;
-        V3<float> ang;
-        float thdd1, thdd2;
-        solve_inv5(K, v5, ap, in, &a0im, &ang, &thdd1, &thdd2);
-        const V3<float> lin = mul(R, cvt<float>(a0im));
+        const V3<float> ang = cvt<float>(r5.al);
+        const float thdd1 = (float)r5.t1, thdd2 = (float)r5.t2;
+        const V3<float> lin = mul(R, cvt<float>(solve_inv5_lin(K, v5, r5)));
         // integrate_motion()'s arithmetic, published as it becomes final
         e.s.vx += h * lin.x; e.s.vy += h * lin.y; e.s.vz += h * lin.z;
         e.s.wx += h * ang.x; e.s.wy += h * ang.y; e.s.wz += h * ang.z;
@@ -289,7 +314,9 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
           if (a.use_pool && live) pool_count(a, have);
           e.episode += 1u;
           e.num_steps = 0;
-          e.flags |= FLAG_ACC_STALE;   // the stored reading is only marked stale (the next step, or a getter that runs first, recomputes it)
+          // without the sensor in the row the stored reading is only marked stale (the next step, or a getter that runs first,
+          // recomputes it); with it, the next round's reading takes its place
+          if (!sens) e.flags |= FLAG_ACC_STALE;
           have = false;
         }
       }
@@ -308,10 +335,15 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
     // (quirk C-6: the reading of the state the step STARTED from; where a reset invalidated it, the flag says so).  The
     // activations are wave B's to store.
     if (live) {
-      const Tether<float> tg = tether_geometry(th1_last, th2_last);
-      const Factor<double> f = mass_factor<true>(e.M, tg, a.h);
-      const Rhs<double> r = reduce_rhs<true>(f, ap_last, in_last);
-      e.acc = rc_sensor(f, r, R, w0);
+      if (sens) {
+        // acc_step is the half round's reading (at s_T), acc_before the last step's: a lane the last step reset keeps mj_forward's
+        e.acc = mark_prev != 0u ? acc_step : acc_before;
+      } else {
+        const Tether<float> tg = tether_geometry(th1_last, th2_last);
+        const Factor<double> f = mass_factor<true>(e.M, tg, a.h);
+        const Rhs<double> r = reduce_rhs<true>(f, ap_last, in_last);
+        e.acc = rc_sensor(f, r, R, w0);
+      }
       float4* g = a.g;
       const int np = a.npad;
       g[G_POS * np + i] = make_float4(e.s.px, e.s.py, e.s.pz, e.s.th1);
@@ -332,15 +364,19 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       const uint32_t mark = rl_get<true, true>(L.st, lane, ed.s);
       const uint4 info = L.info[lane];   // of s_t (wave A rewrites it in phase 2)
       const bool rst = mark != 0u;
-#if !RL_REWARD_IN_D
-      const State<float> sr = ed.s;   // the state the reward of step t - 1 is of: before a reset
-#endif
       rl_take_reset<true, true>(L, lane, mark, ed.s);
       // the activations survive a reset (reference quirk C-2) -- unless they diverged: MuJoCo's bad-state check would have called
       // mj_resetData, which zeroes them (reset_bookkeeping)
       if (rst && !(fabsf(e.s.a0) + fabsf(e.s.a1) + fabsf(e.s.a2) + fabsf(e.s.a3) < 1e10f)) e.s.a0 = e.s.a1 = e.s.a2 = e.s.a3 = 0.f;
       ed.s.a0 = e.s.a0; ed.s.a1 = e.s.a1; ed.s.a2 = e.s.a2; ed.s.a3 = e.s.a3;   // a_t
-      if (t < T) {
+      // the reading of the step that led here (published in the solver wave's last phase 2, rewritten in its next): the sensor entries
+      // of this round's row -- except for a lane that was reset, whose entries wait for this round's reading (wave D fills them in)
+      V3<float> acc_row = mk<float>(0.f, 0.f, 0.f);
+      if (sens && t >= 1) {
+        const float4 x = L.accv[lane];
+        if (!rst) acc_row = mk<float>(x.x, x.y, x.z);
+      }
+      if (t < T || sens) {
         M3<float> Rb;
         V3<float> vb;
         attitude_min(ed.s, &Rb, &vb);
@@ -351,7 +387,7 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         L.appB[0][lane] = make_float4(ap.F.x, ap.F.y, ap.F.z, ap.t1);
         L.appB[1][lane] = make_float4(ap.Tq.x, ap.Tq.y, ap.Tq.z, 0.f);
         // ctrl map and activation filter: a_{t+1}, the part of the Euler step that does not wait for the accelerations
-        rc_filter<SPEC>(a, e.M, e.s, act_now);
+        if (t < T) rc_filter<SPEC>(a, e.M, e.s, act_now);
         RL_STAMP(1);
         coop_barrier();   // 1
         RL_STAMP(2);
@@ -363,35 +399,13 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         if (rst && a.ref_mode != QD_REF_STATIC) moving_reference(a, i, 0, ed.ref);   // a new episode's first row
         float sv[33];
         M3<float> Rq;
-        drone_state<float, true>(ed.s, mk<float>(0.f, 0.f, 0.f), ed.ref, e.par, sv, &Rq);
+        drone_state<float, true>(ed.s, acc_row, ed.ref, e.par, sv, &Rq);
         write_obs_row<true, SPEC>(a, ed, sv, &Rq, L.tile[t & 1] + lane * D);
-#if !RL_REWARD_IN_D
-        const float act4[4] = {act_prev.x, act_prev.y, act_prev.z, act_prev.w};
-        const bool simple = spec_term<SPEC>(a) == QD_TERM_SIMPLE;
-        float rw;
-        if (simple) {   // SimpleDrone.step's reward on this model (env_step: 0.1 - |pos - ref|)
-          const float dx = sr.px - ref_t[0], dy = sr.py - ref_t[1], dz = sr.pz - ref_t[2];
-          rw = 0.1f - qsqrt(dx * dx + dy * dy + dz * dz);
-        } else {
-          rw = reward<float>(spec_reward<SPEC>(a), sv, act4, (int)info.z, ref_t, a.max_distance, &Rq);
-          if (__any(rst ? 1 : 0)) {
-            float sv2[33];
-            M3<float> Rq2;
-            drone_state<float, true>(sr, mk<float>(0.f, 0.f, 0.f), ref_t, e.par, sv2, &Rq2);
-            const float rw2 = reward<float>(spec_reward<SPEC>(a), sv2, act4, (int)info.z, ref_t, a.max_distance, &Rq2);
-            if (rst) rw = rw2;
-          }
-        }
-        if (live) {
-          __builtin_nontemporal_store(rw, reward_out + (size_t)(t - 1) * n + i);
-          __builtin_nontemporal_store((uint8_t)(info.x & 1u), trunc_out + (size_t)(t - 1) * n + i);
-        }
-#endif
       }
       act_prev = act_now;
       if (t + 1 < T) act_now = actions4[(size_t)(t + 1) * n + il];   // for round t + 1: in flight across the barrier
       RL_STAMP(3);
-      if (t < T) coop_barrier();   // 2
+      if (t < T || sens) coop_barrier();   // 2
       RL_STAMP(4);
     }
     coop_barrier();   // X
@@ -417,7 +431,7 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
     jns.px = jns.py = jns.pz = jns.qw = jns.qx = jns.qy = jns.qz = jns.th1 = jns.th2 = 0.f;
     jns.vx = jns.vy = jns.vz = jns.wx = jns.wy = jns.wz = jns.thd1 = jns.thd2 = jns.a0 = jns.a1 = jns.a2 = jns.a3 = 0.f;
     int jphase = 0;
-    for (int t = 0; t < T; t++) {
+    for (int t = 0; t < T + (sens ? 1 : 0); t++) {   // (sensor-reading rows: one more half round, the forward dynamics at s_T)
       RL_STAMP(0);
       State<float> s;
       const uint32_t mark = rl_get<false, false>(L.st, lane, s);
@@ -492,26 +506,24 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
     }
   } else {
     // ================================================================ wave D: drag on the tether | rewards, flags, row stores
-#if RL_REWARD_IN_D
     float4 act_prev = actions4[il];   // the action of step t - 1 when round t uses it
-#endif
     coop_barrier();   // P
     const int rows = min(64, n - base_env);
     constexpr int SD = spec_obs_dim<SPEC>() > 0 ? spec_obs_dim<SPEC>() : 4;
-    const bool split = !spec_runtime<SPEC>() && rows == 64;
+    const bool split = !spec_runtime<SPEC>() && rows == 64 && !sens;
+    uint32_t mark_before = 0u;   // the lanes the step before the last one reset: their row's sensor entries are due this round
     for (int t = 0; t <= T; t++) {
       RL_STAMP(0);
       State<float> s;
-#if RL_REWARD_IN_D
       const uint32_t mark = rl_get<true, true>(L.st, lane, s);
       const uint4 info = L.info[lane];
       State<float> sr = s;   // the state the reward of step t - 1 is of: before a reset
       rl_take_reset<true, false>(L, lane, mark, s);
-#else
-      const uint32_t mark = rl_get<true, false>(L.st, lane, s);
-      rl_take_reset<true, false>(L, lane, mark, s);
-#endif
-      if (t < T) {
+      // the reading of the step that led here: what the rows of the lanes reset a step earlier still lack (taken here: the solver
+      // wave rewrites it in phase 2)
+      float4 acc_due = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (sens && t >= 1) acc_due = L.accv[lane];
+      if (t < T || sens) {
         M3<float> Rd;
         V3<float> vb;
         attitude_min(s, &Rd, &vb);
@@ -526,7 +538,6 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       // the tile's way out is a round trip through LDS and then the row stores: the reads leave first, the reward runs under them
       float4 tv[SD * 16 / 64 > 0 ? SD * 16 / 64 : 1], tvt = make_float4(0.f, 0.f, 0.f, 0.f);
       if (t >= 2 && split) rl_flush_load<SD>(L.tile[(t - 1) & 1], tv, tvt);
-#if RL_REWARD_IN_D
       if (t >= 1) {
         float ref_t[4];
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
@@ -548,17 +559,33 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         }
       }
       if (t < T) act_prev = actions4[(size_t)t * n + il];   // for round t + 1: issued ahead of the row stores, in flight across the barrier
-#endif
       if (t >= 2) {   // row t - 2: wave B built it a round ago
         float* dst = obs + ((size_t)(t - 2) * n + base_env) * D;
         if (split) rl_flush_store<SD>(dst, tv, tvt);
-        else flush_obs(L.tile[(t - 1) & 1], dst, rows, D);
+        else {
+          if (sens) {   // a lane that step t - 2 reset: its row carries the reading at the new state, i.e. of step t - 1's solve
+            if (mark_before != 0u) {
+              float* row = L.tile[(t - 1) & 1] + lane * D + acc_at;
+              row[0] = acc_due.x; row[1] = acc_due.y; row[2] = acc_due.z;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+          }
+          flush_obs_any<SPEC>(L.tile[(t - 1) & 1], dst, rows, D);
+        }
       }
+      mark_before = mark;
       RL_STAMP(3);
-      if (t < T) coop_barrier();   // 2
+      if (t < T || sens) coop_barrier();   // 2
       RL_STAMP(4);
     }
     coop_barrier();   // X: wave B's last row
+    if (sens && mark_before != 0u) {   // the last row of a lane the last step reset: the half round's reading (at s_T)
+      const float4 x = L.accv[lane];
+      float* row = L.tile[T & 1] + lane * D + acc_at;
+      row[0] = x.x; row[1] = x.y; row[2] = x.z;
+    }
+    if (sens) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
     flush_obs_any<SPEC>(L.tile[T & 1], obs + ((size_t)(T - 1) * n + base_env) * D, rows, D);
   }
 }
@@ -566,12 +593,13 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
 hipError_t launch_rollout_lat(const KArgs& k, int spec, int T, const float* actions, float* obs, float* reward, uint8_t* trunc, hipStream_t stream) {
   KArgs kk = k;
   kk.main_blocks = (k.n + 63) / 64;
-  if (kk.main_blocks > 256 || (spec != SPEC_RMA && spec != SPEC_GENERIC_FS1) || k.obs_needs_acc) return hipErrorInvalidValue;
+  if (kk.main_blocks > 256 || (spec != SPEC_RMA && spec != SPEC_LSTM && spec != SPEC_GENERIC_FS1)) return hipErrorInvalidValue;
   // the workgroup's own sampler (wave C's phase 2): every workgroup has its CU to itself here (launch_rollout_coop on when it pays)
   kk.use_pool = (k.auto_reset && k.sc.random_start != QD_START_FIXED) ? 1 : 0;
   const dim3 grid(kk.main_blocks), block(RL_THREADS);
   (void)hipGetLastError();
   if (spec == SPEC_RMA) hipLaunchKernelGGL((k_rollout_lat<SPEC_RMA>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc);
+  else if (spec == SPEC_LSTM) hipLaunchKernelGGL((k_rollout_lat<SPEC_LSTM>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc);
   else hipLaunchKernelGGL((k_rollout_lat<SPEC_GENERIC_FS1>), grid, block, 0, stream, kk, T, actions, obs, reward, trunc);
   return hipGetLastError();
 }

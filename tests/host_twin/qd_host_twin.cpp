@@ -257,10 +257,14 @@ static void fwd_lat(const double* model16, const double* qpos, const double* qve
   s.vx = qvel[0]; s.vy = qvel[1]; s.vz = qvel[2]; s.wx = qvel[3]; s.wy = qvel[4]; s.wz = qvel[5];
   s.thd1 = qvel[6]; s.thd2 = qvel[7];
   s.a0 = act[0]; s.a1 = act[1]; s.a2 = act[2]; s.a3 = act[3];
-  Accel<T> im;
-  forward_lat<T>(M, s, (T)h, &im);
+  Accel<T> im, ex;
+  V3<T> acc;
+  forward_lat<T>(M, s, (T)h, &im, &ex, &acc);
   out8[0] = im.lin.x; out8[1] = im.lin.y; out8[2] = im.lin.z; out8[3] = im.ang.x; out8[4] = im.ang.y; out8[5] = im.ang.z;
   out8[6] = im.thdd1; out8[7] = im.thdd2;
+  // (the caller's buffer has 19 slots: implicit 8, explicit 8, accelerometer 3 -- forward()'s order is explicit, implicit, sensor)
+  out8[8] = ex.lin.x; out8[9] = ex.lin.y; out8[10] = ex.lin.z; out8[11] = ex.ang.x; out8[12] = ex.ang.y; out8[13] = ex.ang.z;
+  out8[14] = ex.thdd1; out8[15] = ex.thdd2; out8[16] = acc.x; out8[17] = acc.y; out8[18] = acc.z;
 }
 extern "C" {
 void twin_forward_lat_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out8) {

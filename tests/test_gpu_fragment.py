@@ -353,7 +353,7 @@ def test_config5_fragment_equals_per_step_kernel(qd, n):
     e1, _ = bench.make_env("config5", n, 42, "cuda:0")
     e2, _ = bench.make_env("config5", n, 42, "cuda:0")
     e1.vector_reset_tensor(); e2.vector_reset_tensor()
-    assert "k_rollout_coop<2" in e1._dev.fragment_kernel_name()
+    assert ("k_rollout_lat<2>" if n <= 16384 else "k_rollout_coop<2") in e1._dev.fragment_kernel_name()
     g = torch.Generator(device="cuda").manual_seed(5)
     resets = 0
     for rep in range(2):
@@ -376,6 +376,34 @@ def test_config5_fragment_equals_per_step_kernel(qd, n):
     assert resets > 0.002 * n * T          # state_difficulty 0.8: resets do happen inside 96 steps
 
 
+def test_config5_latency_kernel_is_batch_and_cut_invariant(qd):
+    """k_rollout_lat<SPEC_LSTM> (sensor-reading rows: the reading handed over a round late, reset lanes' entries filled in by the store
+    wave, the half round at the end of every fragment): 40 steps at once == 13 + 1 + 26 bit for bit, and 4097 envs == the first 64
+    alone (static reference: config 5's waypoint phase depends on the batch size), including the state and the accelerometer plane"""
+    L, T, N = qd._lib, 40, 4097
+    mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, obs="LocalFrameFullStateEnv", reward="distance_energy_reward_pendulum_en4",
+                                             start=1, random_params=0, auto_reset=1, max_steps=7, seed=13, sdiff=0.8))
+    big, small, cut = mk(N), mk(64), mk(N)
+    for e in (big, small, cut):
+        e.reset()
+        assert "k_rollout_lat<2>" in e.fragment_kernel_name()
+    acts = torch.rand((T, N, 4), device="cuda")
+    Ob, Rb, Tb = _bufs(T, N, 23)
+    big.step_fragment(acts, Ob, Rb, Tb)
+    Os, Rs, Ts = _bufs(T, 64, 23)
+    small.step_fragment(acts[:, :64].contiguous(), Os, Rs, Ts)
+    assert torch.equal(Ob[:, :64], Os) and torch.equal(Rb[:, :64], Rs) and torch.equal(Tb[:, :64], Ts)
+    Oc, Rc, Tc = _bufs(T, N, 23)
+    for lo, hi in ((0, 13), (13, 14), (14, 40)):
+        cut.step_fragment(acts[lo:hi], Oc[lo:hi], Rc[lo:hi], Tc[lo:hi])
+    assert torch.equal(Ob, Oc) and torch.equal(Rb, Rc) and torch.equal(Tb, Tc), "cuts: max |d obs| %.3e" % float((Ob - Oc).abs().max())
+    for x, y in zip(big.get_state(), cut.get_state()):
+        assert torch.equal(x, y)
+    for x, y in zip(big.get_state(), small.get_state()):
+        assert torch.equal(x[:64], y)
+    assert int(Tb.sum()) > 0
+
+
 def test_config5_fragment_is_batch_and_cut_invariant(qd):
     """the sensor pipeline (rows a round late, the extra half round at the end of every fragment) must not make results depend
     on where a run is cut: 40 steps at once == 13 + 1 + 26, and 20000 envs == the first 64 alone... except that config 5's
@@ -384,6 +412,7 @@ def test_config5_fragment_is_batch_and_cut_invariant(qd):
     mk = lambda k: qd.dev.DeviceEnv(make_cfg(L, k, load=True, obs="LocalFrameFullStateEnv", reward="distance_energy_reward_pendulum_en4",
                                              start=1, random_params=0, auto_reset=1, max_steps=7, seed=13, sdiff=0.8))
     big, small, cut = mk(20000), mk(64), mk(20000)
+    small.set_option(L.OPT_LATENCY_KERNEL, 0)   # bit-exactness across batch sizes holds within one kernel family: k_rollout_coop above 16384 envs
     for e in (big, small, cut):
         e.reset()
     assert "k_rollout_coop<2,2>" in big.fragment_kernel_name() and "k_rollout_coop<2,1>" in small.fragment_kernel_name()
@@ -418,8 +447,7 @@ def test_generic_fragment_equals_per_step_kernel(qd, obs, reward, acc_at):
                                              max_steps=8, seed=17))
     a, b = mk(), mk()
     a.reset(); b.reset()
-    # rows that carry the accelerometer: k_rollout_coop's run-time-dispatched instantiation; the others, at this size, k_rollout_lat's
-    assert ("k_rollout_coop<4" if acc_at is not None else "k_rollout_lat<4>") in a.fragment_kernel_name(), a.fragment_kernel_name()
+    assert "k_rollout_lat<4>" in a.fragment_kernel_name(), a.fragment_kernel_name()   # at this size, with or without the sensor in the row
     D = a.D
     g = torch.Generator(device="cuda").manual_seed(2)
     for rep in range(2):
@@ -448,7 +476,7 @@ def test_config5_full_size_fragment_vs_oracle_200_steps(qd, orc):
     n, steps, F, L = 8192, 200, 50, qd._lib
     env, _ = bench.make_env("config5", n, 42, "cuda:0", auto_reset=False)
     env.vector_reset_tensor()
-    assert env._dev.fragment_kernel_name() == "qd::k_rollout_coop<2,1>"
+    assert env._dev.fragment_kernel_name() == "qd::k_rollout_lat<2>"
     q0, v0, a0, _, _ = [x.cpu().numpy().astype(np.float64) for x in env._dev.get_state()]
     raw = env._dev.get_params().cpu().numpy()
     ob = orc.Batch(raw, True, L.OBS_KINDS.index("LocalFrameFullStateEnv"), L.REWARD_KINDS.index("distance_energy_reward_pendulum_en4"),
@@ -595,7 +623,7 @@ def test_pid_fragment_rows_that_carry_the_activations_and_fragment_cuts(qd):
     a, b = mk(), mk()
     for e in (a, b):
         e.reset(); e.pid_reset()
-    assert a.fragment_kernel_name() == "qd::k_rollout_coop<4,1>"
+    assert a.fragment_kernel_name() == "qd::k_rollout_lat<4>"   # (of action fragments; the PID loop below runs k_rollout_coop<4,1,true>)
     O, R, Tr, A = a.rollout_pid(T, want_actions=True)
     worst = 0.0
     for t in range(T):

@@ -353,7 +353,7 @@ def test_latency_pieces_equal_the_monolithic_forward(twin):
     float64; with float32 state / trigonometry / drag and float64 algebra (what the device runs) both are compared with the
     float64 value."""
     rng = np.random.default_rng(79)
-    worst64, worst32, mono32 = 0.0, 0.0, 0.0
+    worst64, worst32, mono32, worst_ex = 0.0, 0.0, 0.0, 0.0
     for k in range(600):
         raw = rand_raw(rng, 1)
         m28 = np.zeros(28)
@@ -363,17 +363,22 @@ def test_latency_pieces_equal_the_monolithic_forward(twin):
         qpos[7:] = rng.normal(0, 0.8, 2)
         qvel = np.concatenate([rng.normal(0, 3, 3), rng.normal(0, 4, 3), rng.normal(0, 3, 2)])
         act = rng.uniform(-0.1, 1.2, 4)
-        o64, o32, l64, l32 = np.zeros(38), np.zeros(38), np.zeros(8), np.zeros(8)
+        o64, o32, l64, l32 = np.zeros(38), np.zeros(38), np.zeros(19), np.zeros(19)
         twin.twin_forward_pair_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o64))
         twin.twin_forward_pair_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o32))
         twin.twin_forward_lat_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l64))
         twin.twin_forward_lat_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l32))
         scale = np.maximum(1.0, np.abs(o64[8:16]))
-        worst64 = max(worst64, float(np.max(np.abs(o64[8:16] - l64) / scale)))
-        worst32 = max(worst32, float(np.max(np.abs(l32 - o64[8:16]) / scale)))
+        worst64 = max(worst64, float(np.max(np.abs(o64[8:16] - l64[:8]) / scale)))
+        worst32 = max(worst32, float(np.max(np.abs(l32[:8] - o64[8:16]) / scale)))
+        # the damping-explicit accelerations and the accelerometer, by the 2 x 2 correction of the implicit solve (explicit_from_implicit)
+        ex_ref = np.concatenate([o64[0:8], o64[16:19]])
+        worst_ex = max(worst_ex, float(np.max(np.abs(ex_ref - l64[8:19]) / np.maximum(1.0, np.abs(ex_ref)))))
         mono32 = max(mono32, float(np.max(np.abs(o32[8:16] - o64[8:16]) / scale)))
     print("latency pieces vs forward() in float64: %.2e; in float32 against the float64 value: %.2e (forward() in float32: %.2e)" % (worst64, worst32, mono32))
     assert worst64 < 1e-11
+    print("explicit accelerations + accelerometer from the implicit solve vs forward() in float64: %.2e" % worst_ex)
+    assert worst_ex < 1e-10
     # float32 inputs: both arrangements are judged against the float64 accelerations.  The latency pieces put the float32 sine /
     # cosine pairs back on the unit circle in float64 (trig_unit) and come out closer than forward(), whose J and B D^-1 B^T see
     # the pairs as they are (measured 7.7e-5 against 1.7e-4 over 2000 states)
