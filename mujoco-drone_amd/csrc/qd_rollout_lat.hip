@@ -173,6 +173,10 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
   // round k + 1's reading -- the row wave leaves those three entries open and the store wave fills them in a round later, before
   // the row goes out.  The fragment's last row needs the reading at s_T: one extra half round (wrenches and solve, nothing integrated).
   const bool sens = SPEC == SPEC_RMA ? false : (SPEC == SPEC_LSTM ? true : a.obs_needs_acc != 0);
+  // Who streams the finished rows out: wave D, behind its reward -- except in train_LSTM.py's configuration, whose pendulum-energy
+  // reward (rewards.py:191-230: ~150 instructions more than distance_energy_reward) makes wave D the last wave of phase 2 by 470
+  // cycles; there the row wave, which has the slack, stores the rows it built a round ago (config 5 at 8192 envs: 1.61 -> 1.4x us)
+  constexpr bool FLUSH_B = SPEC == SPEC_LSTM;
   const int acc_at = sens ? rc_acc_slot(spec_obs<SPEC>(a)) : -1;
   __shared__ RlLds L;
   const int role = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -358,6 +362,8 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
     float4 act_now = actions4[il];                        // u_t when round t uses it
     float4 act_prev = make_float4(0.f, 0.f, 0.f, 0.f);    // u_{t-1}: the reward of step t - 1 reads it
     coop_barrier();   // P
+    const int rows_b = min(64, n - base_env);
+    uint32_t markb_before = 0u;   // FLUSH_B: the lanes reset two steps ago (their row's sensor entries are due when it goes out)
     for (int t = 0; t <= T; t++) {
       RL_STAMP(0);
       EnvRegs ed;   // what write_obs_row reads of an env: its state and reference
@@ -372,9 +378,10 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       // the reading of the step that led here (published in the solver wave's last phase 2, rewritten in its next): the sensor entries
       // of this round's row -- except for a lane that was reset, whose entries wait for this round's reading (wave D fills them in)
       V3<float> acc_row = mk<float>(0.f, 0.f, 0.f);
+      float4 accb_due = make_float4(0.f, 0.f, 0.f, 0.f);
       if (sens && t >= 1) {
-        const float4 x = L.accv[lane];
-        if (!rst) acc_row = mk<float>(x.x, x.y, x.z);
+        accb_due = L.accv[lane];
+        if (!rst) acc_row = mk<float>(accb_due.x, accb_due.y, accb_due.z);
       }
       if (t < T || sens) {
         M3<float> Rb;
@@ -392,6 +399,16 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         coop_barrier();   // 1
         RL_STAMP(2);
       }
+      if (FLUSH_B && t >= 2) {   // row t - 2, built a round ago; a lane that step t - 2 reset gets the reading of step t - 1's solve first
+        if (sens && markb_before != 0u) {
+          float* row = L.tile[(t - 1) & 1] + lane * D + acc_at;
+          row[0] = accb_due.x; row[1] = accb_due.y; row[2] = accb_due.z;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        flush_obs_any<SPEC>(L.tile[(t - 1) & 1], obs + ((size_t)(t - 2) * n + base_env) * D, rows_b, D);
+      }
+      markb_before = mark;
       if (t >= 1) {   // the row of step t - 1 is the observation of s_t; its reward is of the state before a reset
         float ref_t[4];
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
@@ -409,6 +426,16 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       RL_STAMP(4);
     }
     coop_barrier();   // X
+    if (FLUSH_B) {   // the last row (a lane the last step reset: the half round's reading, at s_T)
+      if (sens && markb_before != 0u) {
+        const float4 x = L.accv[lane];
+        float* row = L.tile[T & 1] + lane * D + acc_at;
+        row[0] = x.x; row[1] = x.y; row[2] = x.z;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_wave_barrier();
+      flush_obs_any<SPEC>(L.tile[T & 1], obs + ((size_t)(T - 1) * n + base_env) * D, rows_b, D);
+    }
     if (live) a.g[G_ACT * a.npad + i] = make_float4(e.s.a0, e.s.a1, e.s.a2, e.s.a3);
   } else if (role == 2) {
     // ================================================================ wave C: gravity + velocity products; the reset sampler
@@ -537,7 +564,7 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       }
       // the tile's way out is a round trip through LDS and then the row stores: the reads leave first, the reward runs under them
       float4 tv[SD * 16 / 64 > 0 ? SD * 16 / 64 : 1], tvt = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (t >= 2 && split) rl_flush_load<SD>(L.tile[(t - 1) & 1], tv, tvt);
+      if (!FLUSH_B && t >= 2 && split) rl_flush_load<SD>(L.tile[(t - 1) & 1], tv, tvt);
       if (t >= 1) {
         float ref_t[4];
         rc_ref(a, i, (int)info.z - 1, ref0, ref_t);   // the reference the step ran with (episode step before the increment)
@@ -559,7 +586,7 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
         }
       }
       if (t < T) act_prev = actions4[(size_t)t * n + il];   // for round t + 1: issued ahead of the row stores, in flight across the barrier
-      if (t >= 2) {   // row t - 2: wave B built it a round ago
+      if (!FLUSH_B && t >= 2) {   // row t - 2: wave B built it a round ago
         float* dst = obs + ((size_t)(t - 2) * n + base_env) * D;
         if (split) rl_flush_store<SD>(dst, tv, tvt);
         else {
@@ -580,13 +607,15 @@ __global__ __launch_bounds__(RL_THREADS, 1) void k_rollout_lat(KArgs a, int T, c
       RL_STAMP(4);
     }
     coop_barrier();   // X: wave B's last row
-    if (sens && mark_before != 0u) {   // the last row of a lane the last step reset: the half round's reading (at s_T)
-      const float4 x = L.accv[lane];
-      float* row = L.tile[T & 1] + lane * D + acc_at;
-      row[0] = x.x; row[1] = x.y; row[2] = x.z;
+    if (!FLUSH_B) {
+      if (sens && mark_before != 0u) {   // the last row of a lane the last step reset: the half round's reading (at s_T)
+        const float4 x = L.accv[lane];
+        float* row = L.tile[T & 1] + lane * D + acc_at;
+        row[0] = x.x; row[1] = x.y; row[2] = x.z;
+      }
+      if (sens) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
+      flush_obs_any<SPEC>(L.tile[T & 1], obs + ((size_t)(T - 1) * n + base_env) * D, rows, D);
     }
-    if (sens) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }
-    flush_obs_any<SPEC>(L.tile[T & 1], obs + ((size_t)(T - 1) * n + base_env) * D, rows, D);
   }
 }
 

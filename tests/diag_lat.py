@@ -1,7 +1,7 @@
 """Diagnostic (not a test): k_rollout_lat / k_rollout_coop at BASELINE config 3 -- time per step (plain library) or the four waves'
 timeline of one step (a -DQD_STAMPS build in QD_LIB), for the configuration as it is and with the truncations taken away
 (no in-kernel reset, no sampler job), to tell the step itself from what resets cost.
-usage: [QD_LIB=tests/_build/libqd_stamps.so] python tests/diag_lat.py [envs] [T] [normal|noreset|nopool] [lat|coop]"""
+usage: [QD_LIB=tests/_build/libqd_stamps.so] python tests/diag_lat.py [envs] [T] [normal|noreset|nopool] [lat|coop] [config3|config5]"""
 import ctypes as C
 import os
 import sys
@@ -26,7 +26,12 @@ if mode == "noreset":
     cfg.update(max_steps=10 ** 9, max_distance=1e9)
 if mode == "nopool":
     cfg.update(random_start_pos=False)
-env = ow.LocalFrameRPYParamsEnv(cfg)
+if len(sys.argv) > 5 and sys.argv[5] == "config5":   # train_LSTM.py's configuration: sensor-reading rows, pendulum-energy reward, circle waypoints
+    cfg.update(random_params=False, state_difficulty=0.8, reward_fcn=rewards.distance_energy_reward_pendulum_en4,
+               reference_trajectory={"type": "circle", "radius": 1.0, "frequency": 0.5})
+    env = ow.LocalFrameFullStateEnv(cfg)
+else:
+    env = ow.LocalFrameRPYParamsEnv(cfg)
 if kern == "coop":
     env._dev.set_option(QL.OPT_LATENCY_KERNEL, 0)
 env.vector_reset_tensor()
