@@ -7,7 +7,7 @@ set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 OUT=gpurun_out/prof_r04; RAW=/tmp/prof_raw; mkdir -p $OUT $RAW
 B="--no-extras --no-cpu-baseline"
-K=k_rollout_lat      # config 3 at <= 16384 envs; larger batches and config 5: k_rollout_coop
+K=k_rollout_lat      # configs 3 and 5 at <= 16384 envs; larger batches: k_rollout_coop
 SQC="SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU GRBM_GUI_ACTIVE"
 for part in "$@"; do
 case "$part" in
@@ -41,7 +41,7 @@ c25)
   # configs 2 and 5 at their BASELINE sizes through their fragment kernels: duration, HBM-side traffic, issue-side counters
   export QD_BENCH_RAMP_STEPS=2048
   A="--steps 2048 --warmup 1024"
-  for cfg in "config5 8192 k_rollout_coop 32768" "config2 4096 k_rollout_pair 8192"; do
+  for cfg in "config5 8192 k_rollout_lat 32768" "config2 4096 k_rollout_pair 8192"; do
     set -- $cfg
     rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/${1}t -- python3 bench.py --config $1 --envs $2 $A $B > $OUT/bench_${1}_profiled.json
     rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $RAW/${1}f -- python3 bench.py --config $1 --envs $2 $A $B > /dev/null
