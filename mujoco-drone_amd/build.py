@@ -98,26 +98,64 @@ def needs_build():
     return embedded_hash() != source_hash(_extra_flags())
 
 
+def _closure(path, seen=None):
+    """a translation unit and everything it includes (quoted includes, transitively)"""
+    seen = set() if seen is None else seen
+    if path in seen or not os.path.exists(path):
+        return seen
+    seen.add(path)
+    for inc in included_files(path):
+        _closure(inc, seen)
+    return seen
+
+
+def _object_key(cmd, src):
+    """what one object depends on: its command line (without the output path) and the content of every file it includes"""
+    h = hashlib.sha256(" ".join(cmd).encode())
+    for d in sorted(_closure(src)):
+        h.update(os.path.relpath(d, PKG_DIR).encode() + b"\0" + open(d, "rb").read() + b"\0")
+    return h.hexdigest()[:32]
+
+
 def _compile_and_link(out, hash_define, flags, verbose=False):
-    """every translation unit to an object with its own flags (side by side), then one link"""
+    """every translation unit to an object with its own flags (side by side), then one link.  Objects are kept in
+    QD_OBJ_CACHE (a directory; unset: no cache) under a key of their command and inputs, so that an edit to one unit
+    recompiles that unit only -- a developer convenience, the library's own staleness check is the source hash."""
     import tempfile
     hip = _hipcc()
-    common = [hip, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", *CODEGEN_FLAGS, hash_define, *flags]
+    common = [hip, "-O3", "-std=c++17", "--offload-arch=" + ARCH, "-fPIC", "-fno-gpu-rdc", "-Wno-unused-result", *CODEGEN_FLAGS, *flags]
+    # diagnostic variants only: QD_UNIT_FLAGS="qd_rollout_fused.hip:-DX=1,-DY qd_kernels.hip:-DZ" adds flags to single units
+    unit_extra = {u: f.split(",") for u, f in (w.split(":", 1) for w in os.environ.get("QD_UNIT_FLAGS", "").split())}
+    cache = os.environ.get("QD_OBJ_CACHE")
+    if cache:
+        os.makedirs(cache, exist_ok=True)
     with tempfile.TemporaryDirectory(prefix="qd_build_") as tmpdir:
         procs, objs = [], []
         for src in sources():
-            obj = os.path.join(tmpdir, os.path.basename(src) + ".o")
-            cmd = common + list(UNIT_FLAGS.get(os.path.basename(src), ())) + ["-c", src, "-o", obj]
+            unit = os.path.basename(src)
+            cmd = common + list(UNIT_FLAGS.get(unit, ())) + unit_extra.get(unit, [])
+            if unit == "qd_source_hash.hip":
+                cmd = cmd + [hash_define]
+            obj = os.path.join(tmpdir, unit + ".o")
+            kept = os.path.join(cache, "%s.%s.o" % (unit, _object_key(cmd, src))) if cache and not verbose else None
+            if kept and os.path.exists(kept):
+                objs.append(kept)
+                continue
+            cmd = cmd + ["-c", src, "-o", obj]
             if verbose:
                 cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
                 print(" ".join(cmd), flush=True)
-            procs.append((cmd, subprocess.Popen(cmd)))
+            procs.append((cmd, subprocess.Popen(cmd), obj, kept))
             objs.append(obj)
         # every compiler is waited for before anything is raised: the temporary directory is deleted on the way out, and a sibling
         # still writing its object there would fail for a reason that is not its own
-        failed = [(cmd, p.returncode) for cmd, p in procs if p.wait() != 0]
+        failed = [(cmd, p.returncode) for cmd, p, _, _ in procs if p.wait() != 0]
         if failed:
             raise subprocess.CalledProcessError(failed[0][1], failed[0][0])
+        for _, _, obj, kept in procs:
+            if kept:
+                shutil.copyfile(obj, kept + ".tmp")
+                os.replace(kept + ".tmp", kept)
         subprocess.check_call([hip, "--offload-arch=" + ARCH, "-shared", "-fPIC", "-fno-gpu-rdc", "-o", out] + objs)
 
 
@@ -125,6 +163,8 @@ def build_library(force=False, verbose=False):
     """Compile csrc/*.hip for gfx950 into libqd.so next to this file (only if the sources changed, unless forced)."""
     if not force and not needs_build():
         return LIB
+    if os.environ.get("QD_UNIT_FLAGS"):
+        raise RuntimeError("QD_UNIT_FLAGS is for diagnostic variants (build_variant), not for the library")
     extra = _extra_flags()
     tmp = LIB + ".tmp.%d" % os.getpid()
     try:

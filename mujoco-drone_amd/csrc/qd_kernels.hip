@@ -891,12 +891,6 @@ extern "C" {
 
 const char* qd_last_error(void) { return g_err; }
 int qd_version(void) { return QD_VERSION; }
-#ifndef QD_SOURCE_HASH
-#define QD_SOURCE_HASH ""
-#endif
-// the tag makes the hash findable in the file without loading it (build.py: embedded_hash)
-static const char qd_source_hash_tagged[] = "QD_SOURCE_HASH=" QD_SOURCE_HASH;
-const char* qd_source_hash(void) { return qd_source_hash_tagged + sizeof("QD_SOURCE_HASH=") - 1; }
 #ifdef QD_STAMPS
 int qd_debug_read_stamps(unsigned long long* out_host) {
   return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd_stamps), sizeof(unsigned long long) * 64 * 8) == hipSuccess ? 0 : -4;

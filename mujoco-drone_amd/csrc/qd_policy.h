@@ -55,6 +55,7 @@ struct PolArgs {
   int aux_lds, ld_aux, n_aux;            // auxiliary slice read back by qd_policy_aux (n_aux 0: none)
   int dist;                              // POL_DIST_*: which distribution of distributions.py reads the logits
   long long weights_off;      // float offset of the packed weights in the blob
+  long long wsplit_off;       // float offset of the same weights split into float16 pairs (the specialised kernels, qd_policy_static.h)
   // per-env history rings (see qd_policy_ring in include/qd.h)
   int n_rings, state_floats;                     // floats of history per env
   int ring_rows[POL_MAX_RINGS], ring_width[POL_MAX_RINGS], ring_period[POL_MAX_RINGS];

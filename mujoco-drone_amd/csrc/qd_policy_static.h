@@ -40,9 +40,63 @@ constexpr int sp_base(const SProg& p, int b) {
   for (int i = 0; i < b; i++) off += POL_TILE * sp_ld(p, i);
   return off;
 }
-constexpr int sp_act_floats(const SProg& p) { return sp_base(p, p.n_bufs) + POL_SCRATCH; }
 constexpr int sp_k16(const SProg& p, int k) { return (p.op[k].in_dim + 15) / 16; }
+constexpr int sp_k32(const SProg& p, int k) { return (p.op[k].in_dim + 31) / 32; }
+constexpr bool sp_fused_affine(const SProg& p, int k);
+// ---- the float16 mirror of the activations (see s_dense) ----
+// Dense layers multiply on v_mfma_f32_16x16x32_f16 with every operand split into two halves, x = hi + lo / 2048.  A layer whose
+// whole input slice was written by dense epilogues reads it from a mirror of the activation buffers that already holds the split
+// (two planes of halves, written next to the float32 value); any other layer splits the float32 values as it reads them.
+constexpr bool sp_overlap(int a0, int a1, int b0, int b1) { return a0 < b1 && b0 < a1; }
+constexpr bool sp_mirror_fed(const SProg& p, int k) {
+  const SOp& o = p.op[k];
+  if (o.kind != POL_DENSE || o.in_off % 8) return false;
+  const int lo = o.in_off, hi = o.in_off + o.in_dim, hi_pad = o.in_off + sp_k32(p, k) * 32;
+  for (int c = lo; c < hi; c++) {   // every column comes out of a dense epilogue ...
+    bool cov = false;
+    for (int j = 0; j < p.n_ops; j++)
+      if (p.op[j].kind == POL_DENSE && p.op[j].out_buf == o.in_buf && c >= p.op[j].out_off && c < p.op[j].out_off + p.op[j].out_dim) cov = true;
+    if (!cov) return false;
+  }
+  for (int j = 0; j < p.n_ops; j++) {   // ... and nothing else writes into the (padded) slice
+    const SOp& w = p.op[j];
+    if (w.kind == POL_DENSE || w.kind == POL_RING_PUSH) continue;
+    if (w.kind == POL_AFFINE && j > 0 && sp_fused_affine(p, j - 1)) continue;   // applied inside the dense epilogue
+    const int n = (w.kind == POL_COPY_OBS || w.kind == POL_COPY_PREV) ? w.in_dim : w.kind == POL_LSTM_CELL ? 2 * w.out_dim : w.out_dim;
+    if (w.out_buf == o.in_buf && sp_overlap(w.out_off, w.out_off + n, lo, hi_pad)) return false;
+  }
+  return true;
+}
+constexpr bool sp_out_mirrored(const SProg& p, int k) {   // does a mirror-fed layer read what dense op k writes?
+  const SOp& o = p.op[k];
+  for (int j = 0; j < p.n_ops; j++)
+    if (sp_mirror_fed(p, j) && p.op[j].in_buf == o.out_buf &&
+        sp_overlap(o.out_off, o.out_off + o.out_dim, p.op[j].in_off, p.op[j].in_off + p.op[j].in_dim))
+      return true;
+  return false;
+}
+constexpr int sp_hw(const SProg& p, int b) {   // halves per row of buffer b's mirror (0: no mirror-fed layer reads it)
+  int w = 0;
+  for (int k = 0; k < p.n_ops; k++)
+    if (sp_mirror_fed(p, k) && p.op[k].in_buf == b && p.op[k].in_off + sp_k32(p, k) * 32 > w) w = p.op[k].in_off + sp_k32(p, k) * 32;
+  return w;
+}
+constexpr int sp_hld(const SProg& p, int b) { return sp_hw(p, b) ? sp_hw(p, b) + 8 : 0; }   // +16 bytes: rows start 4 banks apart
+constexpr int sp_hbase(const SProg& p, int b) {   // halves, within one plane
+  int off = 0;
+  for (int i = 0; i < b; i++) off += POL_TILE * sp_hld(p, i);
+  return off;
+}
+constexpr int sp_hplane(const SProg& p) { return sp_hbase(p, p.n_bufs); }
+constexpr int sp_mirror_floats(const SProg& p) { return sp_hplane(p); }   // two planes of halves
+constexpr int sp_act_floats(const SProg& p) { return sp_base(p, p.n_bufs) + sp_mirror_floats(p) + POL_SCRATCH; }
 constexpr int sp_ntiles(const SProg& p, int k) { return (p.op[k].out_dim + 15) / 16; }
+constexpr long long sp_ws_at(const SProg& p, int k) {  // floats, within the split-weight region
+  long long off = 0;
+  for (int i = 0; i < k; i++)
+    if (p.op[i].kind == POL_DENSE) off += (long long)sp_ntiles(p, i) * sp_k32(p, i) * 512;
+  return off;
+}
 constexpr long long sp_w_at(const SProg& p, int k) {  // floats, within the weight region
   long long off = 0;
   for (int i = 0; i < k; i++)
@@ -276,7 +330,8 @@ template <> inline constexpr unsigned fused_const_ops<ArchRmaSmaller> = (1u << 3
 struct SCtx {
   float* lds;
   const float* small;      // LDS mirror of the small region
-  const float4* weights;   // packed weights (workgroup-uniform: with a uniform wave index the tile pointers stay in SGPRs)
+  _Float16* mir;           // the float16 mirror of the activation buffers: hi plane, lo plane sp_hplane halves further
+  const float4* wsplit;    // packed split weights (workgroup-uniform: with a uniform wave index the tile pointers stay in SGPRs)
   int lane;                // every load adds the lane: [tile][kblock][lane][4]
   const float* obs;
   const float* prev_actions;
@@ -289,24 +344,38 @@ struct SCtx {
   unsigned skip_ops;       // bit I set: op I is skipped (fused rollouts: the parameter encoder after the first step); 0 elsewhere
 };
 
-constexpr int SPF = 8;  // k-blocks of the next dense layer requested before the current layer's barrier
+typedef _Float16 pol_h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 pol_h4 __attribute__((ext_vector_type(4)));
+// x = hi + lo / 2048 with hi, lo in float16: hi carries 11 bits, lo the next 11 (scaled by a power of two so that it stays a
+// normal number wherever hi is one); what is left is below 2^-22 |x|.  Out-of-range values saturate (tanh networks never get there).
+__device__ __forceinline__ void pol_split(float x, _Float16& h, _Float16& l) {
+  x = __builtin_amdgcn_fmed3f(x, -6.0e4f, 6.0e4f);
+  h = (_Float16)x;
+  l = (_Float16)((x - (float)h) * 2048.0f);
+}
+
+#ifndef QD_POL_SPF
+#define QD_POL_SPF 4
+#endif
+constexpr int SPF = QD_POL_SPF;  // k-blocks (of 32 inputs) of the next dense layer requested before the current layer's barrier
 template <class A, int I> struct SDense {
-  static constexpr int K16 = I < A::prog.n_ops ? sp_k16(A::prog, I) : 1;
+  static constexpr int K32 = I < A::prog.n_ops ? sp_k32(A::prog, I) : 1;
   static constexpr int NT = I < A::prog.n_ops ? sp_ntiles(A::prog, I) : 1;
   static constexpr int SLOTS = (NT + POL_WAVES - 1) / POL_WAVES;   // tile slots per wave (tile = wave + 4 slot, clamped)
   static constexpr int U0 = sp_min(SLOTS, 4);                      // tiles of the first group
-  static constexpr int PB = sp_min(K16, SPF);                      // prefetched k-blocks (first group only)
+  static constexpr int PB = sp_min(K32, SPF);                      // prefetched k-blocks (first group only)
 };
-template <class A, int I> struct SPre {  // prefetched weights of dense op I (empty if I is past the end)
-  float4 w[SDense<A, I>::PB][SDense<A, I>::U0];
+template <class A, int I> struct SPre {  // prefetched weights of dense op I (empty if I is past the end): [k-block][tile][hi | lo]
+  float4 w[SDense<A, I>::PB][SDense<A, I>::U0][2];
 };
 
+// split weights of one 16-column tile: [k-block of 32][hi | lo][lane][8 halves], W[n = 16 tile + (lane & 15)][k = 32 kb + 8 (lane >> 4) + j]
 template <class A, int I>
 __device__ __forceinline__ const float4* s_tile_ptr(const SCtx& c, int slot) {
-  constexpr int K16 = SDense<A, I>::K16, NT = SDense<A, I>::NT;
-  constexpr long long W4 = I < A::prog.n_ops ? sp_w_at(A::prog, I) / 4 : 0;
+  constexpr int K32 = SDense<A, I>::K32, NT = SDense<A, I>::NT;
+  constexpr long long W4 = I < A::prog.n_ops ? sp_ws_at(A::prog, I) / 4 : 0;
   const int tile = min(c.wave + POL_WAVES * slot, NT - 1);  // waves without a tile in this slot repeat the last one
-  return c.weights + W4 + (size_t)tile * (K16 * 64);
+  return c.wsplit + W4 + (size_t)tile * (K32 * 128);
 }
 
 template <class A, int I>
@@ -316,64 +385,126 @@ __device__ __forceinline__ void s_prefetch(const SCtx& c, SPre<A, I>& pre) {
     for (int u = 0; u < SDense<A, I>::U0; u++) {
       const float4* src = s_tile_ptr<A, I>(c, u);
 #pragma unroll
-      for (int kb = 0; kb < SDense<A, I>::PB; kb++) pre.w[kb][u] = src[kb * 64 + c.lane];
+      for (int kb = 0; kb < SDense<A, I>::PB; kb++) {
+        pre.w[kb][u][0] = src[kb * 128 + c.lane];
+        pre.w[kb][u][1] = src[kb * 128 + 64 + c.lane];
+      }
     }
   }
 }
 
+// One dense layer for the tile's 16 envs.  The product runs transposed, D[n][env] = sum_k W[n][k] x[env][k], with the weights as the
+// MFMA's A operand and the activations as its B operand (both: lane = row + 16 (k / 8), eight consecutive k per lane), so that a
+// lane ends up with FOUR CONSECUTIVE output features of ONE env (D: lane = env + 16 (n / 4)) -- one 16-byte store of the float32
+// values, one 8-byte store per mirror plane.  Three MFMAs per k-block and tile: hi hi into one accumulator, hi lo + lo hi into a
+// second that is scaled by 2^-11 at the end; lo lo (< 2^-22) is dropped.  Against the float32 MFMA (16x16x4: 32 cycles per 4 k)
+// that is 48 cycles per 32 k.
 template <class A, int I>
 __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   constexpr SOp op = A::prog.op[I];
-  constexpr int K16 = SDense<A, I>::K16, NT = SDense<A, I>::NT, SLOTS = SDense<A, I>::SLOTS, PB = SDense<A, I>::PB;
+  constexpr int K32 = SDense<A, I>::K32, NT = SDense<A, I>::NT, SLOTS = SDense<A, I>::SLOTS, PB = SDense<A, I>::PB;
+  constexpr bool MF = sp_mirror_fed(A::prog, I), MO = sp_out_mirrored(A::prog, I);
   constexpr int ld_in = sp_ld(A::prog, op.in_buf), ld_out = sp_ld(A::prog, op.out_buf);
   constexpr int in_base = sp_base(A::prog, op.in_buf) + op.in_off, out_base = sp_base(A::prog, op.out_buf) + op.out_off;
+  constexpr int hld_in = sp_hld(A::prog, op.in_buf), hin_base = sp_hbase(A::prog, op.in_buf) + op.in_off;
+  constexpr int hld_out = sp_hld(A::prog, op.out_buf), hout_base = sp_hbase(A::prog, op.out_buf) + op.out_off;
+  constexpr int HP = sp_hplane(A::prog);
   constexpr int s_at = sp_s_at(A::prog, I);
-  const float* a_ptr = c.lds + in_base + c.li * ld_in + c.lg * 4;
-  float* o_ptr = c.lds + out_base + (4 * c.lg) * ld_out + c.li;
-  const float* bias = c.small + s_at + c.li;
+  constexpr bool VEC = op.out_off % 4 == 0 && op.out_dim % 4 == 0;   // a lane's four features are stored as one vector
+  const float* x_f32 = c.lds + in_base + c.li * ld_in + c.lg * 8;
+  const _Float16* x_mir = c.mir + hin_base + c.li * hld_in + c.lg * 8;
+  float* o_ptr = c.lds + out_base + c.li * ld_out + 4 * c.lg;
+  _Float16* m_ptr = c.mir + hout_base + c.li * hld_out + 4 * c.lg;
+  const float* bias = c.small + s_at + 4 * c.lg;
   constexpr int aff_at = sp_fused_affine(A::prog, I) ? sp_s_at(A::prog, I + 1) : 0;
-  const float* aff = c.small + aff_at + c.li;  // scale at [col], shift at [out_dim + col] of the affine op that follows
+  const float* aff = c.small + aff_at + 4 * c.lg;  // scale at [col], shift at [out_dim + col] of the affine op that follows
 #pragma unroll
   for (int g0 = 0; g0 < SLOTS; g0 += 4) {
     constexpr int UMAX = 4;
     const int U = sp_min(SLOTS - g0, UMAX);  // compile-time after unrolling
-    pol_f32x4 acc[UMAX];
+    pol_f32x4 acc[UMAX], acx[UMAX];
     const float4* wp[UMAX];
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
       if (u < U) {
         const int tile = min(c.wave + POL_WAVES * (g0 + u), NT - 1);
-        const float b = bias[tile * 16];
-        acc[u] = pol_f32x4{b, b, b, b};
+        const float4 b = *reinterpret_cast<const float4*>(bias + tile * 16);
+        acc[u] = pol_f32x4{b.x, b.y, b.z, b.w};
+        acx[u] = pol_f32x4{0.f, 0.f, 0.f, 0.f};
         wp[u] = s_tile_ptr<A, I>(c, g0 + u);
       }
     }
 #pragma unroll
-    for (int kb = 0; kb < K16; kb++) {
-      const float4 a = *reinterpret_cast<const float4*>(a_ptr + kb * 16);
-      float4 w[UMAX];
+    for (int kb = 0; kb < K32; kb++) {
+      pol_h8 xh, xl;
+      if constexpr (MF) {
+        xh = *reinterpret_cast<const pol_h8*>(x_mir + kb * 32);
+        xl = *reinterpret_cast<const pol_h8*>(x_mir + HP + kb * 32);
+      } else {
+        const float4 v0 = *reinterpret_cast<const float4*>(x_f32 + kb * 32), v1 = *reinterpret_cast<const float4*>(x_f32 + kb * 32 + 4);
+        const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+          // columns past the slice (the k-block's padding) may hold anything: they count as zero
+          const bool in = (kb + 1) * 32 <= op.in_dim || kb * 32 + c.lg * 8 + j < op.in_dim;
+          _Float16 h, l;
+          pol_split(in ? xv[j] : 0.f, h, l);
+          xh[j] = h; xl[j] = l;
+        }
+      }
+      float4 w[UMAX][2];
 #pragma unroll
       for (int u = 0; u < UMAX; u++)
-        if (u < U) w[u] = (g0 == 0 && kb < PB) ? pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0] : wp[u][kb * 64 + c.lane];
+        if (u < U) {
+          if (g0 == 0 && kb < PB) {
+            w[u][0] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][0];
+            w[u][1] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][1];
+          } else {
+            w[u][0] = wp[u][kb * 128 + c.lane];
+            w[u][1] = wp[u][kb * 128 + 64 + c.lane];
+          }
+        }
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w[u].x, acc[u], 0, 0, 0);
+      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xh, acc[u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w[u].y, acc[u], 0, 0, 0);
+      for (int u = 0; u < UMAX; u++) if (u < U) acx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xl, acx[u], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w[u].z, acc[u], 0, 0, 0);
-#pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w[u].w, acc[u], 0, 0, 0);
+      for (int u = 0; u < UMAX; u++) if (u < U) acx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][1]), xh, acx[u], 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
       if (u < U) {
         const int tile = c.wave + POL_WAVES * (g0 + u);
-        if (tile < NT && tile * 16 + c.li < op.out_dim) {
+        if (tile < NT && tile * 16 + 4 * c.lg < op.out_dim) {
+          float y[4];
 #pragma unroll
           for (int v = 0; v < 4; v++) {
-            float y = pol_act(acc[u][v], op.act);
-            if constexpr (sp_fused_affine(A::prog, I)) y = fmaf(y, aff[tile * 16], aff[op.out_dim + tile * 16]);  // eval-mode BatchNorm
-            o_ptr[v * ld_out + tile * 16] = y;
+            y[v] = pol_act(fmaf(acx[u][v], 1.0f / 2048.0f, acc[u][v]), op.act);
+            if constexpr (sp_fused_affine(A::prog, I)) y[v] = fmaf(y[v], aff[tile * 16 + v], aff[op.out_dim + tile * 16 + v]);  // eval-mode BatchNorm
+          }
+          if constexpr (VEC) {
+            *reinterpret_cast<float4*>(o_ptr + tile * 16) = make_float4(y[0], y[1], y[2], y[3]);
+          } else {
+#pragma unroll
+            for (int v = 0; v < 4; v++)
+              if (tile * 16 + 4 * c.lg + v < op.out_dim) o_ptr[tile * 16 + v] = y[v];
+          }
+          if constexpr (MO) {
+            pol_h4 h, l;
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+              _Float16 hh, ll;
+              pol_split(y[v], hh, ll);
+              h[v] = hh; l[v] = ll;
+            }
+            if constexpr (VEC) {
+              *reinterpret_cast<pol_h4*>(m_ptr + tile * 16) = h;
+              *reinterpret_cast<pol_h4*>(m_ptr + HP + tile * 16) = l;
+            } else {
+#pragma unroll
+              for (int v = 0; v < 4; v++)
+                if (tile * 16 + 4 * c.lg + v < op.out_dim) { m_ptr[tile * 16 + v] = h[v]; m_ptr[HP + tile * 16 + v] = l[v]; }
+            }
           }
         }
       }
@@ -565,7 +696,8 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   c.tid = threadIdx.x; c.wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   const int lane = c.tid & 63;
   c.li = lane & 15; c.lg = lane >> 4;
-  c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
+  c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
+  c.wsplit = reinterpret_cast<const float4*>(p.packed + p.wsplit_off); c.lane = lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter; c.skip_ops = 0u;
@@ -589,6 +721,11 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   SLead<A, 0, LC> lead;
   lead.load(c);
   s_zero_pads<A, 0>(c);
+  {  // the mirror's padding columns meet zero weights, but must not hold NaNs either
+    constexpr int M4 = sp_mirror_floats(A::prog) / 4;
+    float4* mz = reinterpret_cast<float4*>(lds + sp_base(A::prog, A::prog.n_bufs));
+    for (int k = c.tid; k < M4; k += POL_THREADS) mz[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   __syncthreads();
   {
     float4* dst = reinterpret_cast<float4*>(lds + ACT);

@@ -27,6 +27,11 @@
 #include <cstdlib>
 
 #define QD_POL_SECOND_UNIT
+// weights of the next layer requested ahead of the barrier: two k-blocks here (four in k_policy_static) -- under this kernel's
+// 256-register cap four cost 70 spilled registers and 1.1 us per step (6.84 against 5.74, RMA_full at 4096 envs)
+#ifndef QD_POL_SPF
+#define QD_POL_SPF 2
+#endif
 #include "qd_env_device.h"
 #include "qd_policy_static.h"
 
@@ -158,6 +163,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
   constexpr bool sens = SPEC == SPEC_LSTM;
   constexpr int acc_at = 12, act_at = 15;   // rc_acc_slot(OBS_FULLSTATE); the activations follow the reading (qd_obsrew.h)
   static_assert(fp_min_barriers<A>() >= 3, "three layer barriers per step carry the three env stages");
+  static_assert(sp_hw(A::prog, 0) == 0 && sp_hw(A::prog, 1) == 0, "buffers 0 and 1 are written outside the program (staged inputs, patches): float32 only");
   extern __shared__ float lds[];
   __shared__ FpLds L;
   constexpr int IN_FLOATS_ = POL_TILE * (sp_ld(A::prog, 0) + sp_ld(A::prog, 1));
@@ -187,7 +193,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     // ==================================================================== waves 0..3: the network
     SCtx c;
     c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
-    c.weights = reinterpret_cast<const float4*>(p.packed + p.weights_off); c.lane = lane;
+    c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
+    c.wsplit = reinterpret_cast<const float4*>(p.packed + p.wsplit_off); c.lane = lane;
     c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
     c.n_envs = rows; c.env0 = 0; c.want_value = want_value;
     c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
