@@ -31,7 +31,7 @@ CODEGEN_FLAGS = ("-mllvm", "-amdgpu-kernarg-preload-count=5")
 # issue-bound waves of the persistent kernel that is a loss (same box, alternating runs: 1.485 -> 1.347 us per step at 4096 envs,
 # config 5 at 8192 envs 1.946 -> 1.847); the per-step kernels of qd_kernels.hip measured the other way in round 2 and keep it.
 UNIT_FLAGS = {"qd_rollout_coop.hip": ("-fno-slp-vectorize",), "qd_rollout_fused.hip": ("-fno-slp-vectorize",),
-              "qd_rollout_lat.hip": ("-fno-slp-vectorize",)}
+              "qd_rollout_fused32.hip": ("-fno-slp-vectorize",), "qd_rollout_lat.hip": ("-fno-slp-vectorize",)}
 HASH_TAG = b"QD_SOURCE_HASH="
 
 

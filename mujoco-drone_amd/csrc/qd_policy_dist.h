@@ -26,8 +26,11 @@ constexpr int POL_DIST_BETA = 0, POL_DIST_SQUASHED_GAUSSIAN = 1;  // = QD_DIST_*
 #ifndef QD_POL_THREADS
 #define QD_POL_THREADS 256
 #endif
-constexpr int POL_TILE = 16, POL_THREADS = QD_POL_THREADS;  // envs per workgroup (the MFMA M tile), threads per workgroup
-constexpr int POL_SCRATCH = 64;  // floats reserved behind the activation buffers for the per-env log-prob reduction
+#ifndef QD_POL_TILE
+#define QD_POL_TILE 16   // 32 in qd_rollout_fused32.hip only: two 16-env MFMA blocks per workgroup share every weight they load
+#endif
+constexpr int POL_TILE = QD_POL_TILE, POL_THREADS = QD_POL_THREADS;  // envs per workgroup (M tiles of 16), threads per workgroup
+constexpr int POL_SCRATCH = 4 * POL_TILE;  // floats reserved behind the activation buffers for the per-env log-prob reduction
 
 struct PolSample {
   int explore;             // 0: deterministic_sample, 1: sample

@@ -346,14 +346,31 @@ struct SCtx {
 
 typedef _Float16 pol_h8 __attribute__((ext_vector_type(8)));
 typedef _Float16 pol_h4 __attribute__((ext_vector_type(4)));
-// x = hi + lo / 2048 with hi, lo in float16: hi carries 11 bits, lo the next 11 (scaled by a power of two so that it stays a
-// normal number wherever hi is one); what is left is below 2^-22 |x|.  Out-of-range values saturate (tanh networks never get there).
-__device__ __forceinline__ void pol_split(float x, _Float16& h, _Float16& l) {
-  x = __builtin_amdgcn_fmed3f(x, -6.0e4f, 6.0e4f);
-  h = (_Float16)x;
-  l = (_Float16)((x - (float)h) * 2048.0f);
+typedef _Float16 pol_h2 __attribute__((ext_vector_type(2)));
+typedef float pol_f32x2 __attribute__((ext_vector_type(2)));
+// x = hi + lo / 2048 with hi, lo in float16: hi = x cut to 11 significant bits (a mask; exact in float16, so the packed conversion
+// v_cvt_pk_f16_f32 does not round), lo = what is left, scaled by a power of two so that it stays a normal number wherever hi is
+// one, rounded to 11 bits: the pair misses x by less than 2^-21 |x|.  BOUNDED: the values are known to lie inside float16's range
+// (tanh outputs); otherwise they saturate at +-6e4 (no network of the reference gets there).  Below 6e-5 hi rounds to a
+// subnormal: an absolute error under 3e-8.  Four values at a time: 4 masks, 4 subtractions, 4 products, 4 packed conversions.
+template <bool BOUNDED>
+__device__ __forceinline__ void pol_split4(const float (&x)[4], pol_h4& h, pol_h4& l) {
+  float t[4], r[4];
+#pragma unroll
+  for (int v = 0; v < 4; v++) {
+    const float c = BOUNDED ? x[v] : __builtin_amdgcn_fmed3f(x[v], -6.0e4f, 6.0e4f);
+    t[v] = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, c) & 0xFFFFE000u);
+    r[v] = (c - t[v]) * 2048.0f;
+  }
+  const pol_h2 h0 = __builtin_convertvector(pol_f32x2{t[0], t[1]}, pol_h2), h1 = __builtin_convertvector(pol_f32x2{t[2], t[3]}, pol_h2);
+  const pol_h2 l0 = __builtin_convertvector(pol_f32x2{r[0], r[1]}, pol_h2), l1 = __builtin_convertvector(pol_f32x2{r[2], r[3]}, pol_h2);
+  h = pol_h4{h0[0], h0[1], h1[0], h1[1]};
+  l = pol_h4{l0[0], l0[1], l1[0], l1[1]};
 }
 
+constexpr int POL_MB = POL_TILE / 16;   // 16-env MFMA blocks per workgroup
+constexpr int POL_UMAX = 4 / POL_MB;    // output tiles a wave accumulates at a time: 4 x 1 block or 2 x 2 blocks, 32 accumulator registers
+static_assert(POL_MB == 1 || POL_MB == 2, "POL_TILE is 16 or 32");
 #ifndef QD_POL_SPF
 #define QD_POL_SPF 4
 #endif
@@ -362,7 +379,7 @@ template <class A, int I> struct SDense {
   static constexpr int K32 = I < A::prog.n_ops ? sp_k32(A::prog, I) : 1;
   static constexpr int NT = I < A::prog.n_ops ? sp_ntiles(A::prog, I) : 1;
   static constexpr int SLOTS = (NT + POL_WAVES - 1) / POL_WAVES;   // tile slots per wave (tile = wave + 4 slot, clamped)
-  static constexpr int U0 = sp_min(SLOTS, 4);                      // tiles of the first group
+  static constexpr int U0 = sp_min(SLOTS, POL_UMAX);               // tiles of the first group
   static constexpr int PB = sp_min(K32, SPF);                      // prefetched k-blocks (first group only)
 };
 template <class A, int I> struct SPre {  // prefetched weights of dense op I (empty if I is past the end): [k-block][tile][hi | lo]
@@ -393,12 +410,12 @@ __device__ __forceinline__ void s_prefetch(const SCtx& c, SPre<A, I>& pre) {
   }
 }
 
-// One dense layer for the tile's 16 envs.  The product runs transposed, D[n][env] = sum_k W[n][k] x[env][k], with the weights as the
-// MFMA's A operand and the activations as its B operand (both: lane = row + 16 (k / 8), eight consecutive k per lane), so that a
-// lane ends up with FOUR CONSECUTIVE output features of ONE env (D: lane = env + 16 (n / 4)) -- one 16-byte store of the float32
-// values, one 8-byte store per mirror plane.  Three MFMAs per k-block and tile: hi hi into one accumulator, hi lo + lo hi into a
-// second that is scaled by 2^-11 at the end; lo lo (< 2^-22) is dropped.  Against the float32 MFMA (16x16x4: 32 cycles per 4 k)
-// that is 48 cycles per 32 k.
+// One dense layer for the tile's envs, 16 at a time (POL_MB blocks).  The product runs transposed, D[n][env] = sum_k W[n][k] x[env][k],
+// with the weights as the MFMA's A operand and the activations as its B operand (both: lane = row + 16 (k / 8), eight consecutive k
+// per lane), so that a lane ends up with FOUR CONSECUTIVE output features of ONE env (D: lane = env + 16 (n / 4)) -- one 16-byte
+// store of the float32 values, one 8-byte store per mirror plane.  Three MFMAs per k-block, tile and env block: hi hi into one
+// accumulator, hi lo + lo hi into a second that is scaled by 2^-11 at the end; lo lo (< 2^-22) is dropped.  Against the float32
+// MFMA (16x16x4: 32 cycles per 4 k) that is 48 cycles per 32 k.  With two env blocks every weight register is used twice.
 template <class A, int I>
 __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   constexpr SOp op = A::prog.op[I];
@@ -411,6 +428,7 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   constexpr int HP = sp_hplane(A::prog);
   constexpr int s_at = sp_s_at(A::prog, I);
   constexpr bool VEC = op.out_off % 4 == 0 && op.out_dim % 4 == 0;   // a lane's four features are stored as one vector
+  constexpr int MB = POL_MB, UMAX = POL_UMAX;
   const float* x_f32 = c.lds + in_base + c.li * ld_in + c.lg * 8;
   const _Float16* x_mir = c.mir + hin_base + c.li * hld_in + c.lg * 8;
   float* o_ptr = c.lds + out_base + c.li * ld_out + 4 * c.lg;
@@ -419,37 +437,45 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   constexpr int aff_at = sp_fused_affine(A::prog, I) ? sp_s_at(A::prog, I + 1) : 0;
   const float* aff = c.small + aff_at + 4 * c.lg;  // scale at [col], shift at [out_dim + col] of the affine op that follows
 #pragma unroll
-  for (int g0 = 0; g0 < SLOTS; g0 += 4) {
-    constexpr int UMAX = 4;
+  for (int g0 = 0; g0 < SLOTS; g0 += UMAX) {
     const int U = sp_min(SLOTS - g0, UMAX);  // compile-time after unrolling
-    pol_f32x4 acc[UMAX], acx[UMAX];
+    pol_f32x4 acc[UMAX][MB], acx[UMAX][MB];
     const float4* wp[UMAX];
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
       if (u < U) {
         const int tile = min(c.wave + POL_WAVES * (g0 + u), NT - 1);
         const float4 b = *reinterpret_cast<const float4*>(bias + tile * 16);
-        acc[u] = pol_f32x4{b.x, b.y, b.z, b.w};
-        acx[u] = pol_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int eb = 0; eb < MB; eb++) {
+          acc[u][eb] = pol_f32x4{b.x, b.y, b.z, b.w};
+          acx[u][eb] = pol_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
         wp[u] = s_tile_ptr<A, I>(c, g0 + u);
       }
     }
 #pragma unroll
     for (int kb = 0; kb < K32; kb++) {
-      pol_h8 xh, xl;
-      if constexpr (MF) {
-        xh = *reinterpret_cast<const pol_h8*>(x_mir + kb * 32);
-        xl = *reinterpret_cast<const pol_h8*>(x_mir + HP + kb * 32);
-      } else {
-        const float4 v0 = *reinterpret_cast<const float4*>(x_f32 + kb * 32), v1 = *reinterpret_cast<const float4*>(x_f32 + kb * 32 + 4);
-        const float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+      pol_h8 xh[MB], xl[MB];
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-          // columns past the slice (the k-block's padding) may hold anything: they count as zero
-          const bool in = (kb + 1) * 32 <= op.in_dim || kb * 32 + c.lg * 8 + j < op.in_dim;
-          _Float16 h, l;
-          pol_split(in ? xv[j] : 0.f, h, l);
-          xh[j] = h; xl[j] = l;
+      for (int eb = 0; eb < MB; eb++) {
+        if constexpr (MF) {
+          xh[eb] = *reinterpret_cast<const pol_h8*>(x_mir + eb * 16 * hld_in + kb * 32);
+          xl[eb] = *reinterpret_cast<const pol_h8*>(x_mir + eb * 16 * hld_in + HP + kb * 32);
+        } else {
+          const float* xp = x_f32 + eb * 16 * ld_in + kb * 32;
+          const float4 v0 = *reinterpret_cast<const float4*>(xp), v1 = *reinterpret_cast<const float4*>(xp + 4);
+          float xv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+          if ((kb + 1) * 32 > op.in_dim) {   // (compile-time once unrolled) columns past the slice, the k-block's padding, may hold anything: they count as zero
+#pragma unroll
+            for (int j = 0; j < 8; j++) xv[j] = kb * 32 + c.lg * 8 + j < op.in_dim ? xv[j] : 0.f;
+          }
+          pol_h4 ha, la, hb, lb;
+          const float xa[4] = {xv[0], xv[1], xv[2], xv[3]}, xb[4] = {xv[4], xv[5], xv[6], xv[7]};
+          pol_split4<false>(xa, ha, la);
+          pol_split4<false>(xb, hb, lb);
+          xh[eb] = pol_h8{ha[0], ha[1], ha[2], ha[3], hb[0], hb[1], hb[2], hb[3]};
+          xl[eb] = pol_h8{la[0], la[1], la[2], la[3], lb[0], lb[1], lb[2], lb[3]};
         }
       }
       float4 w[UMAX][2];
@@ -465,45 +491,54 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
           }
         }
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acc[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xh, acc[u], 0, 0, 0);
+      for (int u = 0; u < UMAX; u++)
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xl, acx[u], 0, 0, 0);
+        for (int eb = 0; eb < MB; eb++)
+          if (u < U) acc[u][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xh[eb], acc[u][eb], 0, 0, 0);
 #pragma unroll
-      for (int u = 0; u < UMAX; u++) if (u < U) acx[u] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][1]), xh, acx[u], 0, 0, 0);
+      for (int u = 0; u < UMAX; u++)
+#pragma unroll
+        for (int eb = 0; eb < MB; eb++)
+          if (u < U) acx[u][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][0]), xl[eb], acx[u][eb], 0, 0, 0);
+#pragma unroll
+      for (int u = 0; u < UMAX; u++)
+#pragma unroll
+        for (int eb = 0; eb < MB; eb++)
+          if (u < U) acx[u][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][1]), xh[eb], acx[u][eb], 0, 0, 0);
     }
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
       if (u < U) {
         const int tile = c.wave + POL_WAVES * (g0 + u);
         if (tile < NT && tile * 16 + 4 * c.lg < op.out_dim) {
-          float y[4];
 #pragma unroll
-          for (int v = 0; v < 4; v++) {
-            y[v] = pol_act(fmaf(acx[u][v], 1.0f / 2048.0f, acc[u][v]), op.act);
-            if constexpr (sp_fused_affine(A::prog, I)) y[v] = fmaf(y[v], aff[tile * 16 + v], aff[op.out_dim + tile * 16 + v]);  // eval-mode BatchNorm
-          }
-          if constexpr (VEC) {
-            *reinterpret_cast<float4*>(o_ptr + tile * 16) = make_float4(y[0], y[1], y[2], y[3]);
-          } else {
-#pragma unroll
-            for (int v = 0; v < 4; v++)
-              if (tile * 16 + 4 * c.lg + v < op.out_dim) o_ptr[tile * 16 + v] = y[v];
-          }
-          if constexpr (MO) {
-            pol_h4 h, l;
+          for (int eb = 0; eb < MB; eb++) {
+            float y[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) {
-              _Float16 hh, ll;
-              pol_split(y[v], hh, ll);
-              h[v] = hh; l[v] = ll;
+              y[v] = pol_act(fmaf(acx[u][eb][v], 1.0f / 2048.0f, acc[u][eb][v]), op.act);
+              if constexpr (sp_fused_affine(A::prog, I)) y[v] = fmaf(y[v], aff[tile * 16 + v], aff[op.out_dim + tile * 16 + v]);  // eval-mode BatchNorm
             }
+            float* o = o_ptr + eb * 16 * ld_out + tile * 16;
             if constexpr (VEC) {
-              *reinterpret_cast<pol_h4*>(m_ptr + tile * 16) = h;
-              *reinterpret_cast<pol_h4*>(m_ptr + HP + tile * 16) = l;
+              *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
             } else {
 #pragma unroll
               for (int v = 0; v < 4; v++)
-                if (tile * 16 + 4 * c.lg + v < op.out_dim) { m_ptr[tile * 16 + v] = h[v]; m_ptr[HP + tile * 16 + v] = l[v]; }
+                if (tile * 16 + 4 * c.lg + v < op.out_dim) o[v] = y[v];
+            }
+            if constexpr (MO) {
+              pol_h4 h, l;
+              pol_split4<op.act == POL_ACT_TANH && !sp_fused_affine(A::prog, I)>(y, h, l);
+              _Float16* m = m_ptr + eb * 16 * hld_out + tile * 16;
+              if constexpr (VEC) {
+                *reinterpret_cast<pol_h4*>(m) = h;
+                *reinterpret_cast<pol_h4*>(m + HP) = l;
+              } else {
+#pragma unroll
+                for (int v = 0; v < 4; v++)
+                  if (tile * 16 + 4 * c.lg + v < op.out_dim) { m[v] = h[v]; m[HP + v] = l[v]; }
+              }
             }
           }
         }

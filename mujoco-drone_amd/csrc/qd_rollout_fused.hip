@@ -584,6 +584,12 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
 }
 
 // ---- host ----
+// dynamic LDS of one instantiation: activations + mirror + scratch, the small region, the observation / action tiles, flags, z stash
+template <int SPEC, class A>
+constexpr size_t fp_lds_bytes() {
+  return ((size_t)sp_act_floats(A::prog) + sp_small_floats(A::prog) + POL_TILE * (A::prog.obs_dim + A::prog.act_dim) + 16 + POL_TILE * 8) * sizeof(float);
+}
+
 hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa, size_t lds_bytes, int T, const PolSample& smp,
                                      const float* obs0, const float* prev0, float* obs, float* actions, float* reward, uint8_t* trunc,
                                      float* logp, float* logits, float* value, hipStream_t stream) {
@@ -595,16 +601,17 @@ hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa
   // more dynamic LDS than the default limit: the instantiation opts in (160 KB per CU on gfx950), once per process and arch
 #define FP_LAUNCH(SPECV, ARCH)                                                                                                        \
   do {                                                                                                                                \
-    if (lds_bytes > 64 * 1024) {                                                                                                      \
+    const size_t lds_ = lds_bytes > fp_lds_bytes<SPECV, ARCH>() ? lds_bytes : fp_lds_bytes<SPECV, ARCH>();                            \
+    if (lds_ > 64 * 1024) {                                                                                                           \
       static size_t opted = 0;                                                                                                        \
-      if (lds_bytes > opted) {                                                                                                        \
+      if (lds_ > opted) {                                                                                                             \
         const hipError_t e_ = hipFuncSetAttribute(reinterpret_cast<const void*>(k_rollout_fused_pipe<SPECV, ARCH>),                   \
-                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);                        \
+                                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_);                             \
         if (e_ != hipSuccess) return e_;                                                                                              \
-        opted = lds_bytes;                                                                                                            \
+        opted = lds_;                                                                                                                 \
       }                                                                                                                               \
     }                                                                                                                                 \
-    hipLaunchKernelGGL((k_rollout_fused_pipe<SPECV, ARCH>), grid, block, lds_bytes, stream, kk, pa, T, smp, obs0, prev0, obs, actions, \
+    hipLaunchKernelGGL((k_rollout_fused_pipe<SPECV, ARCH>), grid, block, lds_, stream, kk, pa, T, smp, obs0, prev0, obs, actions,     \
                        reward, trunc, logp, logits, value);                                                                           \
   } while (0)
   switch (arch) {
@@ -621,7 +628,20 @@ hipError_t launch_rollout_fused_pipe(int arch, const KArgs& k, const PolArgs& pa
 
 }  // namespace qd
 
-#ifdef QD_STAMPS
+#if QD_POL_TILE == 32
+// qd_rollout_fused32.hip compiles this file a second time with 32 envs per workgroup, in a namespace of its own; the library's
+// host side (qd_policy_host.inc) reaches that copy through this plain entry point.  KArgs / PolArgs / PolSample are the same
+// structs in both copies.
+extern "C" int qd_fused32_launch(int arch, const void* k, const void* pa, int T, const void* smp, const float* obs0, const float* prev0,
+                                 float* obs, float* actions, float* reward, uint8_t* trunc, float* logp, float* logits, float* value,
+                                 void* stream) {
+  return (int)qd::launch_rollout_fused_pipe(arch, *static_cast<const qd::KArgs*>(k), *static_cast<const qd::PolArgs*>(pa), 0, T,
+                                            *static_cast<const qd::PolSample*>(smp), obs0, prev0, obs, actions, reward, trunc, logp,
+                                            logits, value, static_cast<hipStream_t>(stream));
+}
+#endif
+
+#if defined(QD_STAMPS) && QD_POL_TILE == 16
 extern "C" int qd_debug_read_fpstamps(unsigned long long* out_host) {
   return (int)hipMemcpyFromSymbol(out_host, HIP_SYMBOL(qd::qd_fpstamps), sizeof(qd::qd_fpstamps));
 }

@@ -197,9 +197,12 @@ def test_policy_exploring_rollout_is_a_sample_batch(PG, kernel):
     assert float(out["actions"].std()) > 0.05
 
 
-def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
+@pytest.mark.parametrize("tile", [16, 32])
+def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch, tile):
     """k_rollout_fused_pipe (one launch per fragment, the env step beside the forward pass) against the per-step path driven from Python (qd_policy_act + qd_step),
-    deterministic and exploring, with in-kernel auto-resets (truncation every 9 steps) and a ragged env count"""
+    deterministic and exploring, with in-kernel auto-resets (truncation every 9 steps) and a ragged env count; both copies of the
+    kernel (16 and 32 envs per workgroup: qd_rollout_fused.hip / qd_rollout_fused32.hip)"""
+    monkeypatch.setenv("QD_FUSED_TILE", str(tile))
     from mujoco_drone_amd.policy import DevicePolicy
     from mujoco_drone_amd.environments.BaseDroneEnv import base_config
     from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
@@ -236,10 +239,16 @@ def test_fused_rollout_equals_two_launch_loop(PG, monkeypatch):
                 np.testing.assert_allclose(x, y, atol=2e-5)
 
 
-def test_pipelined_rollout_many_workgroups_distance_truncation_moving_reference(PG, monkeypatch):
-    """k_rollout_fused_pipe (env step beside the forward pass) past one workgroup per CU: 4096 + 37 envs = 259 workgroups, the last one
-    ragged; truncation by distance as well as by step count (max_distance 0.35 at state_difficulty 1), a circling waypoint, and the
-    arena left as the per-step path leaves it.  Reference: qd_policy_act + qd_step per step on a twin env fed the same actions."""
+@pytest.mark.parametrize("tile", [16, 0])
+def test_pipelined_rollout_many_workgroups_distance_truncation_moving_reference(PG, monkeypatch, tile):
+    """k_rollout_fused_pipe (env step beside the forward pass) past one workgroup per CU: 4096 + 37 envs = 259 workgroups of 16 (forced)
+    or, as the library chooses above 4096 envs, 130 of 32, the last one ragged; truncation by distance as well as by step count
+    (max_distance 0.35 at state_difficulty 1), a circling waypoint, and the arena left as the per-step path leaves it.
+    Reference: qd_policy_act + qd_step per step on a twin env fed the same actions."""
+    if tile:
+        monkeypatch.setenv("QD_FUSED_TILE", str(tile))
+    else:
+        monkeypatch.delenv("QD_FUSED_TILE", raising=False)
     from mujoco_drone_amd.policy import DevicePolicy
     from mujoco_drone_amd.environments.BaseDroneEnv import base_config
     from mujoco_drone_amd.environments.observation_wrappers import LocalFrameRPYParamsEnv
