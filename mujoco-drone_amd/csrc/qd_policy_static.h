@@ -331,8 +331,14 @@ struct SCtx {
   float* lds;
   const float* small;      // LDS mirror of the small region
   _Float16* mir;           // the float16 mirror of the activation buffers: hi plane, lo plane sp_hplane halves further
-  const float4* wsplit;    // packed split weights (workgroup-uniform: with a uniform wave index the tile pointers stay in SGPRs)
-  int lane;                // every load adds the lane: [tile][kblock][lane][4]
+  // packed split weights, read through a buffer descriptor: the address of a load is descriptor (4 SGPRs) + a scalar byte offset
+  // (tile, k-block: wave-uniform) + ONE vector register (16 lane) that every load of the kernel shares.  With plain pointers the
+  // compiler kept a 64-bit vector address per 4 KB window of every layer alive across the fused rollout's step loop: 50-70 spilled
+  // registers under that kernel's 256-register cap.
+  __amdgpu_buffer_rsrc_t wrs;
+  const char* wbase;
+  int lane16;
+  int lane;
   const float* obs;
   const float* prev_actions;
   const uint8_t* prev_truncated;
@@ -386,13 +392,26 @@ template <class A, int I> struct SPre {  // prefetched weights of dense op I (em
   float4 w[SDense<A, I>::PB][SDense<A, I>::U0][2];
 };
 
-// split weights of one 16-column tile: [k-block of 32][hi | lo][lane][8 halves], W[n = 16 tile + (lane & 15)][k = 32 kb + 8 (lane >> 4) + j]
+typedef unsigned pol_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t pol_weight_rsrc(const float* base) {
+  // raw buffer (stride 0), bounds wide open: the offsets are compile-time functions of the program
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ float4 pol_wload(const SCtx& c, int byte_off) {
+#ifdef QD_POL_GLOBAL_LOADS   // A/B builds only
+  return *reinterpret_cast<const float4*>(c.wbase + byte_off + c.lane16);
+#else
+  return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.lane16, byte_off, 0));
+#endif
+}
+// split weights of one 16-column tile: [k-block of 32][hi | lo][lane][8 halves], W[n = 16 tile + (lane & 15)][k = 32 kb + 8 (lane >> 4) + j];
+// returns the tile's byte offset in the split region (wave-uniform)
 template <class A, int I>
-__device__ __forceinline__ const float4* s_tile_ptr(const SCtx& c, int slot) {
+__device__ __forceinline__ int s_tile_off(const SCtx& c, int slot) {
   constexpr int K32 = SDense<A, I>::K32, NT = SDense<A, I>::NT;
-  constexpr long long W4 = I < A::prog.n_ops ? sp_ws_at(A::prog, I) / 4 : 0;
+  constexpr int W0 = I < A::prog.n_ops ? (int)(sp_ws_at(A::prog, I) * 4) : 0;
   const int tile = min(c.wave + POL_WAVES * slot, NT - 1);  // waves without a tile in this slot repeat the last one
-  return c.wsplit + W4 + (size_t)tile * (K32 * 128);
+  return W0 + tile * (K32 * 2048);
 }
 
 template <class A, int I>
@@ -400,11 +419,11 @@ __device__ __forceinline__ void s_prefetch(const SCtx& c, SPre<A, I>& pre) {
   if constexpr (I < A::prog.n_ops) {
 #pragma unroll
     for (int u = 0; u < SDense<A, I>::U0; u++) {
-      const float4* src = s_tile_ptr<A, I>(c, u);
+      const int off = s_tile_off<A, I>(c, u);
 #pragma unroll
       for (int kb = 0; kb < SDense<A, I>::PB; kb++) {
-        pre.w[kb][u][0] = src[kb * 128 + c.lane];
-        pre.w[kb][u][1] = src[kb * 128 + 64 + c.lane];
+        pre.w[kb][u][0] = pol_wload(c, off + kb * 2048);
+        pre.w[kb][u][1] = pol_wload(c, off + kb * 2048 + 1024);
       }
     }
   }
@@ -440,7 +459,7 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
   for (int g0 = 0; g0 < SLOTS; g0 += UMAX) {
     const int U = sp_min(SLOTS - g0, UMAX);  // compile-time after unrolling
     pol_f32x4 acc[UMAX][MB], acx[UMAX][MB];
-    const float4* wp[UMAX];
+    int wp[UMAX];
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
       if (u < U) {
@@ -451,7 +470,7 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
           acc[u][eb] = pol_f32x4{b.x, b.y, b.z, b.w};
           acx[u][eb] = pol_f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        wp[u] = s_tile_ptr<A, I>(c, g0 + u);
+        wp[u] = s_tile_off<A, I>(c, g0 + u);
       }
     }
 #pragma unroll
@@ -486,8 +505,8 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
             w[u][0] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][0];
             w[u][1] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][1];
           } else {
-            w[u][0] = wp[u][kb * 128 + c.lane];
-            w[u][1] = wp[u][kb * 128 + 64 + c.lane];
+            w[u][0] = pol_wload(c, wp[u] + kb * 2048);
+            w[u][1] = pol_wload(c, wp[u] + kb * 2048 + 1024);
           }
         }
 #pragma unroll
@@ -732,7 +751,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   const int lane = c.tid & 63;
   c.li = lane & 15; c.lg = lane >> 4;
   c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
-  c.wsplit = reinterpret_cast<const float4*>(p.packed + p.wsplit_off); c.lane = lane;
+  c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.wbase = reinterpret_cast<const char*>(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter; c.skip_ops = 0u;

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     SCtx c;
     c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
     c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
-    c.wsplit = reinterpret_cast<const float4*>(p.packed + p.wsplit_off); c.lane = lane;
+    c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.wbase = reinterpret_cast<const char*>(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
     c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
     c.n_envs = rows; c.env0 = 0; c.want_value = want_value;
     c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings
