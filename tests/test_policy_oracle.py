@@ -34,20 +34,21 @@ FAMILY_OF = {"rma_full": "RMA_full", "rma_model": "RMA_model", "simple_mlp": "Si
 @pytest.mark.parametrize("tag", ["rma_full", "rma_model", "simple_mlp", "custom_mlp"])
 def test_policy_programs_compile_on_the_host(PG, tag):
     """state dict -> layer program -> qd_policy_packed_bytes (host-only entry point of the C ABI): the program passes
-    the library's validation and the packed blob has the size the padded 16x16 tiling implies"""
+    the library's validation and the packed blob has the size the padded tilings imply"""
     import ctypes as C
     from mujoco_drone_amd import _lib as L
     from mujoco_drone_amd.policy import compile_program
     d, ops, blob = compile_program(FAMILY_OF[tag], weights_of(PG, tag))
     nbytes = L.lib().qd_policy_packed_bytes(C.byref(d), ops)
     assert nbytes > 0, L.last_error()
-    # [program ints | small floats (biases padded to 16-wide tiles, affine scale / shift) | packed weights]
+    # [program ints | small floats (biases padded to 16-wide tiles, affine scale / shift) | packed float32 weights (the interpreter's) |
+    #  the same weights as float16 pairs in 16 x 32 tiles (the specialised kernels')]
     prog = 16 * len(ops) + 4 * 32          # op descriptors + one sentinel step per wave
     small = weights = 0
     for op in ops:
         if op.kind == L.POL_DENSE:
             k16, nt = (op.in_dim + 15) // 16, (op.out_dim + 15) // 16
-            weights += nt * k16 * 256
+            weights += nt * k16 * 256 + nt * ((op.in_dim + 31) // 32) * 512
             small += nt * 16
             for w in range(4):                                            # per-wave step lists
                 slots = (nt - w + 3) // 4 if w < nt else 0
