@@ -204,7 +204,7 @@ int qd_step_fragment(qd_env* env, const float* actions, int T, float* obs, float
 /* Per-env switches of launch variants (measurements and A/B tests; results do not depend on them beyond rounding).
  *   QD_OPT_PERSISTENT_FRAGMENTS  1 (default): qd_step_fragment / qd_rollout may run as one persistent launch; 0: never.
  *   QD_OPT_LATENCY_KERNEL        1 (default): persistent fragments of at most 16384 envs (256 workgroups, one per CU) of the
- *                                training configuration run k_rollout_lat (csrc/qd_rollout_lat.hip), whose four wavefronts split
+ *                                load model (one substep per step, any observation variant and reward) run k_rollout_lat (csrc/qd_rollout_lat.hip), whose four wavefronts split
  *                                the step for the shortest dependent chain; 0: k_rollout_coop at every size (the variant batches
  *                                above 16384 envs always run: a comparison across the size switch that must be bit-exact sets 0). */
 enum { QD_OPT_PERSISTENT_FRAGMENTS = 0, QD_OPT_LATENCY_KERNEL = 1, QD_OPT_COUNT };

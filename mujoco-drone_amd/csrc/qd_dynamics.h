@@ -410,7 +410,8 @@ QD_HD V3<T> accelerometer(V3<T> a0e, V3<T> ang_ex, V3<T> gt, V3<T> u) {
 //     [thdd1] = [-U1^T  s11   s12 ] [g1 ]        C = J'^-1, U_i = C (e_i B_i), s_ij = delta_ij e_i + (e_i B_i) . U_j
 //     [thdd2]   [-U2^T  s12   s22 ] [g2 ]
 // Only the damping-implicit system (e_i = 1 / (D_i + h b), what the integration uses) is formed: the accelerometer reading needs
-// the explicit one and stays with mass_factor() (sensor-carrying observation variants do not run this path).
+// the explicit one, which differs from it by h b on the two hinge diagonals -- explicit_weights / explicit_from_implicit below
+// get its solution from this one's by a 2 x 2 correction.
 // Same equations as forward(): tests/test_host_twin.py::test_latency_pieces_equal_the_monolithic_forward, 1e-11 in float64.
 template <class HP>
 struct LatConsts {

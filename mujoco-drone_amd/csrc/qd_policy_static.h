@@ -1,5 +1,8 @@
 // qd_policy_static.h -- compile-time specialisations of the policy kernel for the reference's actual networks.
 //
+// (Round 4: the specialised kernels multiply on v_mfma_f32_16x16x32_f16 with every operand split into two float16 halves -- three
+// products per float32 product, 5.3x the rate of the float32 MFMA, as close to the float64 oracle as float32 is; s_dense below.
+// The interpreter keeps v_mfma_f32_16x16x4_f32.)
 // k_policy (qd_policy.h) interprets any layer program, but with ONE wave per SIMD every interpreted step costs ~500
 // instructions at ~5 cycles each: 1.1 us of bookkeeping around 0.1-0.45 us of MFMAs (measured with the stamped
 // build, tests/diag_policy_stamps.py).  The networks the reference actually trains are fixed (train_PPO.py:39-45:
@@ -336,7 +339,6 @@ struct SCtx {
   // compiler kept a 64-bit vector address per 4 KB window of every layer alive across the fused rollout's step loop: 50-70 spilled
   // registers under that kernel's 256-register cap.
   __amdgpu_buffer_rsrc_t wrs;
-  const char* wbase;
   int lane16;
   int lane;
   const float* obs;
@@ -398,11 +400,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t pol_weight_rsrc(const float* b
   return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, 0x7fffffff, 0x00020000);
 }
 __device__ __forceinline__ float4 pol_wload(const SCtx& c, int byte_off) {
-#ifdef QD_POL_GLOBAL_LOADS   // A/B builds only
-  return *reinterpret_cast<const float4*>(c.wbase + byte_off + c.lane16);
-#else
   return __builtin_bit_cast(float4, __builtin_amdgcn_raw_buffer_load_b128(c.wrs, c.lane16, byte_off, 0));
-#endif
 }
 // split weights of one 16-column tile: [k-block of 32][hi | lo][lane][8 halves], W[n = 16 tile + (lane & 15)][k = 32 kb + 8 (lane >> 4) + j];
 // returns the tile's byte offset in the split region (wave-uniform)
@@ -751,7 +749,7 @@ __global__ __launch_bounds__(POL_THREADS) void k_policy_static(PolArgs p, int n_
   const int lane = c.tid & 63;
   c.li = lane & 15; c.lg = lane >> 4;
   c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
-  c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.wbase = reinterpret_cast<const char*>(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
+  c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
   c.obs = obs; c.prev_actions = prev_actions; c.prev_truncated = prev_truncated;
   c.n_envs = n_envs; c.env0 = blockIdx.x * POL_TILE; c.want_value = value != nullptr;
   c.small_global = p.packed + p.prog_ints; c.state = state; c.counter = smp.counter; c.skip_ops = 0u;

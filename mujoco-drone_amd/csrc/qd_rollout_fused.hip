@@ -6,7 +6,7 @@
 // a_{t+1} = a_t + h (clamp(u_t) - a_t) / tau.  Position, attitude, velocities and hinge angles of s_{t+1} -- everything an
 // observation row of the sensor-free variants reads -- do not depend on u_t at all, and neither does the truncation test; only
 // the reward (its energy term) and the four activations do.  So while waves 0..3 of a workgroup run the network on observation
-// o_t (k_policy_static's code: float32 MFMA, activations in LDS), waves 4..7 advance the same 16 envs from s_t to s_{t+1} in the
+// o_t (k_policy_static's code: float16-pair MFMA, activations in LDS), waves 4..7 advance the same 16 envs from s_t to s_{t+1} in the
 // roles of k_rollout_coop (A factorisation / solve / integration / resets, B applied wrench, C inertial wrench, D observation
 // row), 16 lanes each, and have o_{t+1} in LDS long before the network has u_t.  What does read the action runs a pass LATE, off
 // the critical path: wave A applies the filter between the next pass's two gather barriers (waves B and C read the activations
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     SCtx c;
     c.lds = lds; c.small = small; c.tid = tid; c.wave = wave; c.li = lane & 15; c.lg = lane >> 4;
     c.mir = reinterpret_cast<_Float16*>(lds + sp_base(A::prog, A::prog.n_bufs));
-    c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.wbase = reinterpret_cast<const char*>(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
+    c.wrs = pol_weight_rsrc(p.packed + p.wsplit_off); c.lane16 = lane * 16; c.lane = lane;
     c.obs = otile; c.prev_actions = atile; c.prev_truncated = trt;   // the gathers read LDS tiles, rows 0..rows-1
     c.n_envs = rows; c.env0 = 0; c.want_value = want_value;
     c.small_global = p.packed + p.prog_ints; c.state = nullptr; c.counter = 0u;  // feed-forward networks only: no history rings

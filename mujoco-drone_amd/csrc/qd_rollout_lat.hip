@@ -14,16 +14,18 @@
 //                      coefficients, hinges first, adjugate;        | plane as it becomes final, truncation, reset from the pool
 //                      attitude matrix, normalised quaternion       | entry PREFETCHED IN REGISTERS, the quaternion's chain last
 //   wave B (airframe)  motor filter, attitude, rotors, drag on core | the observation row of s_t (= row of step t - 1) into an LDS
-//                      and link                                     | tile, the reward of step t - 1
+//                      and link                                     | tile [SPEC_LSTM: and the stores of row t - 2]
 //   wave C (inertial)  inertial_wrench(s_t)                         | one chunk of the workgroup's reset sampler
-//   wave D (tether)    attitude, tether geometry, drag on the tether| streaming stores of row t - 2
+//   wave D (tether)    attitude, tether geometry, drag on the tether| the reward of step t - 1, streaming stores of row t - 2
 //                    barrier 1 ^                                                                          barrier 2 ^
 //
 // so that phase 1 carries only what the solve waits for, split four ways, and the epilogue lives in phase 2 beside the solve.
 // The arithmetic of the mass matrix is qd_dynamics.h's latency arrangement (lat_consts / mass_inverse / solve_inv5: same
-// equations as mass_factor / reduce_rhs / finish_accel, tests/test_host_twin.py).  Observation variants that carry the
-// accelerometer and the PID action source stay with k_rollout_coop, as do batches of more than 256 workgroups (there the SIMDs'
-// issue slots are the bound and this kernel's duplicated attitude / geometry arithmetic would cost throughput).
+// equations as mass_factor / reduce_rhs / finish_accel, tests/test_host_twin.py).  Rows that carry the accelerometer get the
+// damping-explicit accelerations from the implicit solve by a 2 x 2 correction (explicit_from_implicit) and are handed over a round
+// late (L.accv; in train_LSTM.py's configuration, SPEC_LSTM, the row wave also stores the rows: FLUSH_B).  The PID action source
+// stays with k_rollout_coop, as do batches of more than 256 workgroups (there the SIMDs' issue slots are the bound and this
+// kernel's duplicated attitude / geometry arithmetic would cost throughput).
 #include "qd_env_device.h"
 
 namespace qd {

@@ -69,6 +69,10 @@ policy)
   rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/pol -- python3 tests/diag_fused_stamps.py 4096 > $OUT/r04_policy_loop_wall.txt
   rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $RAW/polq -- python3 tests/diag_fused_stamps.py 4096 > /dev/null
   python3 profiles/summarize.py r04_policy_loop_n4096 $RAW/pol --kernel k_rollout_fused_pipe --out $OUT --grid 131072 --cut 256 --longest 256 --tol 0.85 --pmc sq=$RAW/polq
+  # train_LSTM.py's pair at its 8192 envs: CNNestimator on 23-value rows, 32 envs per workgroup (qd_rollout_fused32.hip)
+  rocprofv3 --kernel-trace --stats --output-format csv -d $RAW/polc -- python3 tests/diag_fused_stamps.py 8192 cnn > $OUT/r04_policy_loop_cnn_wall.txt
+  rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU GRBM_GUI_ACTIVE --output-format csv -d $RAW/polcq -- python3 tests/diag_fused_stamps.py 8192 cnn > /dev/null
+  python3 profiles/summarize.py r04_policy_loop_cnn_n8192 $RAW/polc --kernel k_rollout_fused_pipe --out $OUT --grid 131072 --cut 256 --longest 256 --tol 0.85 --pmc sq=$RAW/polcq
   ;;
 esac
 done
