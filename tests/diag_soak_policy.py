@@ -10,10 +10,11 @@ from mujoco_drone_amd.policy import DevicePolicy, random_weights
 from mujoco_drone_amd.custom_logging import BatchStatistics, EpisodeStatistics
 
 frags = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-n, T = 4096, 1024
-for fam in ("RMA_full", "RMA_full_adapt"):
-    env, _ = bench.make_env("config3", n, 42, "cuda:0")
-    pol = DevicePolicy(fam, random_weights(fam, 3))
+T = 1024
+for fam, conf, n, kw in (("RMA_full", "config3", 4096, {}), ("RMA_full_adapt", "config3", 4096, {}),
+                         ("CNNestimator", "config5", 8192, dict(obs_dim=23, num_states=23))):   # (the last: 32 envs per workgroup)
+    env, _ = bench.make_env(conf, n, 42, "cuda:0")
+    pol = DevicePolicy(fam, random_weights(fam, 3), **kw)
     obs0 = env.vector_reset_tensor().clone()
     if pol.has_history:
         pol.reset_state(n)
@@ -37,7 +38,7 @@ for fam in ("RMA_full", "RMA_full_adapt"):
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     q = env._dev.get_state()[0]
-    dist = float((q[:, :3] - torch.tensor([0, 0, 15.0], device=q.device)).norm(dim=1).max())
+    dist = float((q[:, :3] - torch.tensor([0, 0, 15.0], device=q.device)).norm(dim=1).max()) if conf == "config3" else 0.0   # (config 5's waypoint circles)
     print("%-16s kernel %d: %d fragments x %d steps x %d envs = %.2e env-steps in %.1f s (%.2e /s incl. checks), %d episodes, max |pos - ref| %.3f"
           % (fam, pol.kernel, frags, T, n, frags * T * n, dt, frags * T * n / dt, episodes, dist), flush=True)
     assert dist < 4.5
