@@ -663,7 +663,7 @@ def main():
                     dt = time.perf_counter() - t1
                     extras["policy_closed_loop_env_steps_per_s"] = 1024 * n / dt
                     extras["policy_closed_loop_us_per_step"] = dt / 1024 * 1e6
-                    extras["policy_closed_loop_kernel"] = "qd::k_rollout_fused_pipe (env step beside the forward pass)" if n <= 16384 else "two launches per step"
+                    extras["policy_closed_loop_kernel"] = "qd::k_rollout_fused_pipe (env step beside the forward pass)" if n <= 65536 else "two launches per step"
                     extras["policy_kernel"] = "specialised" if pol.kernel > 0 else "interpreter"
                 for other in ("config2", "config3", "config5"):
                     if other == args.config:
