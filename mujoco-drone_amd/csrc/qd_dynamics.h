@@ -684,6 +684,55 @@ QD_HD void sensor_affine(const Model<T>& M, State<T> s, T h, V3<T>* c0, V3<T> co
   }
 }
 
+// sensor_affine() in the latency arrangement (the closed policy loop's reset lanes, qd_rollout_fused.hip): one mass_inverse serves
+// the five right-hand sides, each solve 5 dot products + the 2 x 2 correction to the explicit system -- 30 registers of inverse
+// where the LDL^T factor holds 100 (k: lat_consts(M, h), which the caller has).  Same reading: tests/test_host_twin.py, against
+// forward() at random activations.
+template <class T>
+QD_HD void sensor_affine_lat(const Model<T>& M, const LatConsts<typename HighPrec<T>::type>& k, State<T> s, V3<T>* c0, V3<T> col[4]) {
+  using HP = typename HighPrec<T>::type;
+  s.a0 = s.a1 = s.a2 = s.a3 = T(0);
+  M3<T> R;
+  V3<T> vb;
+  attitude_min(s, &R, &vb);
+  const V3<T> w = mk<T>(s.wx, s.wy, s.wz);
+  const Tether<T> tg = tether_geometry(s.th1, s.th2);
+  const T g = T(Const::gravity), sz = T(Const::sense_z);
+  const V3<T> gtR = mk<T>(g * R.m20, g * R.m21, g * R.m22);
+  const Applied<T> a1 = applied_core_link<true>(M, s, w, vb, tg.s1, tg.c1, gtR), a2 = applied_tether(M, s, w, vb, tg);
+  Applied<T> ap;
+  ap.F = a1.F + a2.F; ap.Tq = a1.Tq + a2.Tq; ap.t1 = a1.t1 + a2.t1; ap.t2 = a1.t2 + a2.t2;
+  V3<T> gt, w_;
+  gravity_body(s, &gt, &w_);
+  const TetherHP<HP> th = tether_hp<HP>(tg.s1, tg.c1, tg.s2, tg.c2);
+  const Inertial<HP> in = inertial_wrench_hp<T, HP, false>(M, s, gt, w_, th.d, th.y2);
+  const Inv5<HP> v = mass_inverse(k, th);
+  const ExW<HP> xw = explicit_weights(k, v);
+  V3<HP> a0ex;
+  V3<T> ang;
+  T d1, d2;
+  {
+    const Rot5<HP> r = solve_inv5_rot(v, ap, in);
+    explicit_from_implicit(k, v, xw, r.fl, r.al, r.t1, r.t2, &a0ex, &ang, &d1, &d2);
+    *c0 = accelerometer(cvt<T>(a0ex), ang, gtR, mk<T>(w.x * w.z, w.y * w.z, -(w.x * w.x + w.y * w.y)));
+  }
+  Inertial<HP> zero;
+  zero.F = mk<HP>(HP(0), HP(0), HP(0)); zero.Tq = zero.F; zero.t1 = zero.t2 = HP(0);
+  // unit activation of rotor i: thrust gearF along z at (+-rot, +-rot, 0), yaw reaction +-gearT (applied_core_link)
+  const T sx[4] = {T(-1), T(1), T(1), T(-1)}, sy[4] = {T(-1), T(-1), T(1), T(1)}, sg[4] = {T(1), T(-1), T(1), T(-1)};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    Applied<T> d;
+    d.F = mk<T>(T(0), T(0), M.gearF);
+    d.Tq = mk<T>(M.rot * M.gearF * sx[i], M.rot * M.gearF * sy[i], M.gearT * sg[i]);
+    d.t1 = d.t2 = T(0);
+    const Rot5<HP> r = solve_inv5_rot(v, d, zero);
+    explicit_from_implicit(k, v, xw, r.fl, r.al, r.t1, r.t2, &a0ex, &ang, &d1, &d2);
+    const V3<T> a0e = cvt<T>(a0ex);
+    col[i] = mk<T>(a0e.x + ang.y * sz, a0e.y - ang.x * sz, a0e.z);
+  }
+}
+
 // The same forward dynamics as forward() below, composed from the pieces above in one lane (load model).  The step
 // kernels do NOT use it: hipcc schedules the monolithic forward() with fewer live values (36 vs 52 bytes of scratch in the
 // 256-thread instantiation, 12-16 % of the step time in the HBM-bound regime), so forward() stays as it was and the pieces

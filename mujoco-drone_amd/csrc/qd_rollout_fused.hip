@@ -21,7 +21,8 @@
 // new state.  For RMA_full the layers behind those barriers take 1.4 / 2.9 / 1.3 us, the stages 0.5 / 2.0 / 1.1 + 0.4 (stamps,
 // profiles/r03_policy_loop_timeline.txt).  The env waves run at raised priority (s_setprio 3).
 // The 23-value rows of train_LSTM.py's configuration carry the activations and the accelerometer: see SPEC_LSTM in the kernel.
-// Arithmetic: the role functions of qd_dynamics.h on the same values as k_rollout_coop -- equal to the per-step kernels to
+// Arithmetic: qd_dynamics.h's latency arrangement (k_rollout_lat's: mass_inverse / solve_inv5, the accelerometer's explicit
+// accelerations by explicit_from_implicit; a reset lane's affine sensor form stays sensor_affine) -- equal to the per-step kernels to
 // rounding (tests/test_gpu_policy.py compares with the two-launch loop).  Resets sample inline (a pure function of seed, env,
 // episode: the same states the pool would serve), inside the longest layer's window.
 #include <cstdlib>
@@ -309,10 +310,25 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     }
     if (lane == 0) L.tag = 0;
     coop_barrier();   // P
-    Factor<double> f;
-    Rhs<double> r;
+    // the mass matrix in qd_dynamics.h's latency arrangement (k_rollout_lat's arithmetic: per-env coefficients once, hinges first,
+    // the 3 x 3 that is left by its adjugate, the solve as dot products; 60 registers across the layer barrier where the LDL^T
+    // factor held 100)
+    const LatConsts<double> K = lat_consts(e.M, a.h);
+    Inv5<double> v5 = {};
+    Rot5<double> r5 = {};
     M3<float> R;
+    R.m00 = R.m11 = R.m22 = 1.f; R.m01 = R.m02 = R.m10 = R.m12 = R.m20 = R.m21 = 0.f;
     V3<float> w0 = mk<float>(0.f, 0.f, 0.f);
+    // the accelerometer reading of the last solve: the explicit accelerations from the implicit ones (explicit_from_implicit)
+    auto reading = [&]() {
+      V3<double> a0ex;
+      V3<float> angex;
+      float d1, d2;
+      explicit_from_implicit(K, v5, explicit_weights(K, v5), r5.fl, r5.al, r5.t1, r5.t2, &a0ex, &angex, &d1, &d2);
+      const float g = float(Const::gravity);
+      return accelerometer(cvt<float>(a0ex), angex, mk<float>(g * R.m20, g * R.m21, g * R.m22),
+                           mk<float>(w0.x * w0.z, w0.y * w0.z, -(w0.x * w0.x + w0.y * w0.y)));
+    };
     // the part of the Euler step that reads the action: the activation filter.  It runs a pass LATE, between the next pass's two
     // gather barriers -- waves B and C read the activations behind the second one -- so that the network never waits for it.
     V3<float> sc0 = mk<float>(0.f, 0.f, 0.f), scol[4] = {sc0, sc0, sc0, sc0}, acc_last = sc0;   // sens: a reset lane's affine form, the last reading
@@ -345,12 +361,11 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       // ---------------------------------------------------------- stage 1
       if (col) {
         const Tether<float> tg = tether_geometry(e.s.th1, e.s.th2);
-        f = mass_factor<true>(e.M, tg, a.h);
+        v5 = mass_inverse(K, tether_hp<double>(tg.s1, tg.c1, tg.s2, tg.c2));
         rc_ref(a, i, e.num_steps, ref0, e.ref);
-        rc_pin(f.B1); rc_pin(f.B2); rc_pin(f.X1); rc_pin(f.X2); rc_pin(f.rc);
-        rc_pin(f.s11, f.s12, f.s22); rc_pin(f.imt, f.m2, f.hb);
-        rc_pin(f.Sm); rc_pin(f.kp1); rc_pin(f.kp2);
-        rc_pin(f.idet_ex, f.idet_im, f.hb); rc_pin(f.ixx, f.ixy, f.ixz); rc_pin(f.iyy, f.iyz, f.izz);
+        // everything the solve reads exists BEFORE the barrier (the barrier is an asm the compiler moves pure arithmetic across)
+        rc_pin(v5.cxx, v5.cxy, v5.cxz); rc_pin(v5.cyy, v5.cyz, v5.czz); rc_pin(v5.U1); rc_pin(v5.U2);
+        rc_pin(v5.s11, v5.s12, v5.s22); rc_pin(v5.rc); rc_pin(v5.kp1); rc_pin(v5.kp2);
       }
       FP_STAMP(17);
       coop_barrier();   // layer barrier 1
@@ -369,18 +384,17 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
             const double2 y0 = L.ine[0][lane], y1 = L.ine[1][lane], y2 = L.ine[2][lane], y3 = L.ine[3][lane];
             in.F = mk<double>(y0.x, y0.y, y1.x); in.Tq = mk<double>(y1.y, y2.x, y2.y); in.t1 = y3.x; in.t2 = y3.y;
           }
-          r = reduce_rhs<true>(f, ap, in);
+          r5 = solve_inv5_rot(v5, ap, in);
         }
         w0 = mk<float>(e.s.wx, e.s.wy, e.s.wz);
         if (sens) {   // the reading of this step (the ONLY place it is evaluated: the arena gets the same bits)
-          acc_last = rc_sensor(f, r, R, w0);
+          acc_last = reading();
           L.acc[lane] = make_float4(acc_last.x, acc_last.y, acc_last.z, 0.f);
         }
         pend = false;
         Accel<float> im;
-        V3<double> a0im;
-        finish_accel<true, true>(f, r, &a0im, &im.ang, &im.thdd1, &im.thdd2);
-        im.lin = mul(R, cvt<float>(a0im));
+        im.ang = cvt<float>(r5.al); im.thdd1 = (float)r5.t1; im.thdd2 = (float)r5.t2;
+        im.lin = mul(R, cvt<float>(solve_inv5_lin(K, v5, r5)));
         integrate_motion<float, true>(e.s, im, a.h);
         e.flags &= ~FLAG_ACC_STALE;
         e.num_steps += 1;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
           e.s = ns;
           reset_bookkeeping(e.s, e.episode, e.num_steps);
           if (sens) {
-            sensor_affine<float>(e.M, e.s, a.h, &sc0, scol);
+            sensor_affine_lat<float>(e.M, K, e.s, &sc0, scol);
             pend = true;
           } else {
             e.flags |= FLAG_ACC_STALE;
@@ -422,7 +436,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
     filter(T - 1);   // the last step's
     // what a per-step launch leaves in the arena: the state, and the reading of the last step (quirk C-6; stale where that step reset)
     if (live) {
-      e.acc = sens ? acc_last : rc_sensor(f, r, R, w0);
+      e.acc = sens ? acc_last : reading();   // (v5, r5, R, w0: the last step's)
       store_env(a, i, e);
     }
   } else if (role == 1) {
@@ -435,13 +449,19 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         State<float> s;
         fp_get_state(L.st, lane, s);
         const Tether<float> tg = tether_geometry(s.th1, s.th2);
-        const Att<float> at = attitude(s);
-        const Applied<float> ap = applied_wrench(e.M, s, at, tg);
-        L.app[0][lane] = make_float4(ap.F.x, ap.F.y, ap.F.z, ap.t1);
-        L.app[1][lane] = make_float4(ap.Tq.x, ap.Tq.y, ap.Tq.z, ap.t2);
-        L.app[2][lane] = make_float4(at.R.m00, at.R.m01, at.R.m02, at.R.m10);
-        L.app[3][lane] = make_float4(at.R.m11, at.R.m12, at.R.m20, at.R.m21);
-        L.app[4][lane] = make_float4(at.R.m22, 0.f, 0.f, 0.f);
+        M3<float> Rb;
+        V3<float> vb;
+        attitude_min(s, &Rb, &vb);
+        const V3<float> w = mk<float>(s.wx, s.wy, s.wz);
+        const float g = float(Const::gravity);
+        // rotors + drag on core and link (minus the core body's inertial share: forward_lat's split), drag on the tether
+        const Applied<float> a1 = applied_core_link<true>(e.M, s, w, vb, tg.s1, tg.c1, mk<float>(g * Rb.m20, g * Rb.m21, g * Rb.m22));
+        const Applied<float> a2 = applied_tether(e.M, s, w, vb, tg);
+        L.app[0][lane] = make_float4(a1.F.x + a2.F.x, a1.F.y + a2.F.y, a1.F.z + a2.F.z, a1.t1 + a2.t1);
+        L.app[1][lane] = make_float4(a1.Tq.x + a2.Tq.x, a1.Tq.y + a2.Tq.y, a1.Tq.z + a2.Tq.z, a1.t2 + a2.t2);
+        L.app[2][lane] = make_float4(Rb.m00, Rb.m01, Rb.m02, Rb.m10);
+        L.app[3][lane] = make_float4(Rb.m11, Rb.m12, Rb.m20, Rb.m21);
+        L.app[4][lane] = make_float4(Rb.m22, 0.f, 0.f, 0.f);
       }
       coop_barrier();   // layer barrier 1
       coop_barrier();   // layer barrier 2
@@ -458,9 +478,10 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         State<float> s;
         fp_get_state(L.st, lane, s);
         const Tether<float> tg = tether_geometry(s.th1, s.th2);
+        const TetherHP<double> th = tether_hp<double>(tg.s1, tg.c1, tg.s2, tg.c2);   // the same pairs the solver wave builds its inverse from
         V3<float> gt, w;
         gravity_body(s, &gt, &w);
-        const Inertial<double> in = inertial_wrench(e.M, s, gt, w, tg);
+        const Inertial<double> in = inertial_wrench_hp<float, double, false>(e.M, s, gt, w, th.d, th.y2);   // the core body's share: wave B
         L.ine[0][lane] = make_double2(in.F.x, in.F.y);
         L.ine[1][lane] = make_double2(in.F.z, in.Tq.x);
         L.ine[2][lane] = make_double2(in.Tq.y, in.Tq.z);

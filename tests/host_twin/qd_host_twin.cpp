@@ -298,3 +298,29 @@ void twin_sensor_affine_f64(const double* model16, const double* qpos, const dou
   out6[3] = acc.x; out6[4] = acc.y; out6[5] = acc.z;
 }
 }
+// the same reading from the latency arrangement's affine form (sensor_affine_lat), float64 and float32
+template <class T>
+static void affine_lat(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out3) {
+  Model<T> M;
+  T* mp = reinterpret_cast<T*>(&M);
+  for (int i = 0; i < MODEL_FLOATS; i++) mp[i] = (T)model16[i];
+  State<T> s;
+  s.px = (T)qpos[0]; s.py = (T)qpos[1]; s.pz = (T)qpos[2]; s.qw = (T)qpos[3]; s.qx = (T)qpos[4]; s.qy = (T)qpos[5]; s.qz = (T)qpos[6];
+  s.th1 = (T)qpos[7]; s.th2 = (T)qpos[8];
+  s.vx = (T)qvel[0]; s.vy = (T)qvel[1]; s.vz = (T)qvel[2]; s.wx = (T)qvel[3]; s.wy = (T)qvel[4]; s.wz = (T)qvel[5];
+  s.thd1 = (T)qvel[6]; s.thd2 = (T)qvel[7];
+  s.a0 = (T)act[0]; s.a1 = (T)act[1]; s.a2 = (T)act[2]; s.a3 = (T)act[3];
+  V3<T> c0, col[4];
+  sensor_affine_lat<T>(M, lat_consts(M, (T)h), s, &c0, col);
+  out3[0] = c0.x + s.a0 * col[0].x + s.a1 * col[1].x + s.a2 * col[2].x + s.a3 * col[3].x;
+  out3[1] = c0.y + s.a0 * col[0].y + s.a1 * col[1].y + s.a2 * col[2].y + s.a3 * col[3].y;
+  out3[2] = c0.z + s.a0 * col[0].z + s.a1 * col[1].z + s.a2 * col[2].z + s.a3 * col[3].z;
+}
+extern "C" {
+void twin_sensor_affine_lat_f64(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out3) {
+  affine_lat<double>(model16, qpos, qvel, act, h, out3);
+}
+void twin_sensor_affine_lat_f32(const double* model16, const double* qpos, const double* qvel, const double* act, double h, double* out3) {
+  affine_lat<float>(model16, qpos, qvel, act, h, out3);
+}
+}

@@ -389,7 +389,7 @@ def test_sensor_is_affine_in_the_activations(twin):
     """sensor_affine (qd_dynamics.h): c0 + sum a_i col_i equals the accelerometer of forward() at the same state and
     activations -- what lets the reset pool prepare a new episode's first sensor reading before the activations are known"""
     rng = np.random.default_rng(78)
-    worst = 0.0
+    worst = worst_lat = worst_lat32 = 0.0
     for k in range(300):
         raw = rand_raw(rng, 1)
         m28 = np.zeros(28)
@@ -402,5 +402,11 @@ def test_sensor_is_affine_in_the_activations(twin):
         o = np.zeros(6)
         twin.twin_sensor_affine_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(o))
         worst = max(worst, float(np.max(np.abs(o[:3] - o[3:]) / np.maximum(1.0, np.abs(o[3:])))))
-    print("affine sensor vs forward(): %.2e" % worst)
-    assert worst < 1e-11
+        # the latency arrangement's form (the closed policy loop's reset lanes): float64 against forward(), float32 against float64
+        l64, l32 = np.zeros(3), np.zeros(3)
+        twin.twin_sensor_affine_lat_f64(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l64))
+        twin.twin_sensor_affine_lat_f32(P(m28), P(qpos), P(qvel), P(act), C.c_double(0.01), P(l32))
+        worst_lat = max(worst_lat, float(np.max(np.abs(l64 - o[3:]) / np.maximum(1.0, np.abs(o[3:])))))
+        worst_lat32 = max(worst_lat32, float(np.max(np.abs(l32 - o[3:]) / np.maximum(1.0, np.abs(o[3:])))))
+    print("affine sensor vs forward(): %.2e; latency form %.2e (float64), %.2e (float32)" % (worst, worst_lat, worst_lat32))
+    assert worst < 1e-11 and worst_lat < 1e-11 and worst_lat32 < 2e-5
