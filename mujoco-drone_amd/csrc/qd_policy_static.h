@@ -471,6 +471,23 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
         wp[u] = s_tile_off<A, I>(c, g0 + u);
       }
     }
+    // The weights run PB k-blocks ahead of the MFMAs through a ring of registers: the loads of block kb + PB leave when block kb
+    // is taken out of the ring.  (Left to itself the compiler requests a block where it is used and keeps three or four loads in
+    // flight -- the 256 -> 128 layer then waits for L2 once per k-block: 2.3 us for 0.33 us of MFMAs.)
+    float4 wq[PB][UMAX][2];
+#pragma unroll
+    for (int d = 0; d < PB; d++)
+#pragma unroll
+      for (int u = 0; u < UMAX; u++)
+        if (u < U) {
+          if (g0 == 0) {
+            wq[d][u][0] = pre.w[d][u < SDense<A, I>::U0 ? u : 0][0];
+            wq[d][u][1] = pre.w[d][u < SDense<A, I>::U0 ? u : 0][1];
+          } else {
+            wq[d][u][0] = pol_wload(c, wp[u] + d * 2048);
+            wq[d][u][1] = pol_wload(c, wp[u] + d * 2048 + 1024);
+          }
+        }
 #pragma unroll
     for (int kb = 0; kb < K32; kb++) {
       pol_h8 xh[MB], xl[MB];
@@ -499,13 +516,8 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
 #pragma unroll
       for (int u = 0; u < UMAX; u++)
         if (u < U) {
-          if (g0 == 0 && kb < PB) {
-            w[u][0] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][0];
-            w[u][1] = pre.w[kb < PB ? kb : 0][u < SDense<A, I>::U0 ? u : 0][1];
-          } else {
-            w[u][0] = pol_wload(c, wp[u] + kb * 2048);
-            w[u][1] = pol_wload(c, wp[u] + kb * 2048 + 1024);
-          }
+          w[u][0] = wq[kb % PB][u][0];
+          w[u][1] = wq[kb % PB][u][1];
         }
 #pragma unroll
       for (int u = 0; u < UMAX; u++)
@@ -522,6 +534,16 @@ __device__ __forceinline__ void s_dense(const SCtx& c, const SPre<A, I>& pre) {
 #pragma unroll
         for (int eb = 0; eb < MB; eb++)
           if (u < U) acx[u][eb] = __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(pol_h8, w[u][1]), xh[eb], acx[u][eb], 0, 0, 0);
+      if (kb + PB < K32) {   // the slot is free: block kb + PB takes it, requested HERE (the fences keep the scheduler from moving the loads to their uses)
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < UMAX; u++)
+          if (u < U) {
+            wq[kb % PB][u][0] = pol_wload(c, wp[u] + (kb + PB) * 2048);
+            wq[kb % PB][u][1] = pol_wload(c, wp[u] + (kb + PB) * 2048 + 1024);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #pragma unroll
     for (int u = 0; u < UMAX; u++) {
