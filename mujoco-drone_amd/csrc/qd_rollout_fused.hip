@@ -16,7 +16,8 @@
 //
 // gfx950 has ONE barrier per workgroup, so the env waves pass exactly the barriers the network executes: two at the input
 // gather, one per executed layer, one behind the outputs.  The env stages sit in front of the first three layer barriers: stage 1
-// (the three role waves) before the first, stage 2 (wave A: solve, integration, termination, reset) before the second, wave D's
+// (the three role waves) before the first, stage 2 (wave A: solve, integration, termination, reset) before the second -- started
+// as soon as the other role waves have counted themselves in, with the first layer barrier passed in its middle --, wave D's
 // staging of the next pass's inputs before the third; wave D's row waits for no barrier but polls a tag wave A writes behind the
 // new state.  For RMA_full the layers behind those barriers take 1.4 / 2.9 / 1.3 us, the stages 0.5 / 2.0 / 1.1 + 0.4 (stamps,
 // profiles/r03_policy_loop_timeline.txt).  The env waves run at raised priority (s_setprio 3).
@@ -48,6 +49,7 @@ struct FpLds {                 // the env waves' hand-over: one column per env o
   uint4 info[POL_TILE];        // A -> D: (bit 0 truncated | bit 1 reset), episode counter, num_steps after the step, -
   float4 acc[POL_TILE];        // A -> D: the accelerometer reading in the row of this step (sensor-carrying rows; not for reset lanes)
   int tag;                     // A -> D: t + 1 once st / pre / info of step t are published (wave D polls it: no barrier of its own to wait at)
+  unsigned int ready;          // B, C, D -> A: + 1 each once a pass's wrenches are written / its reward is settled (3 (t + 1): stage 2 of pass t may start)
 };
 
 __device__ __forceinline__ void fp_put_state(float4 (*st)[POL_TILE], int lane, const State<float>& s) {
@@ -308,7 +310,7 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       fp_put_state(L.st, lane, e.s);
       L.info[lane] = make_uint4(0u, e.episode, (uint32_t)e.num_steps, 0u);
     }
-    if (lane == 0) L.tag = 0;
+    if (lane == 0) { L.tag = 0; L.ready = 0u; }
     coop_barrier();   // P
     // the mass matrix in qd_dynamics.h's latency arrangement (k_rollout_lat's arithmetic: per-env coefficients once, hinges first,
     // the 3 x 3 that is left by its adjugate, the solve as dot products; 60 registers across the layer barrier where the LDL^T
@@ -368,9 +370,26 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         rc_pin(v5.s11, v5.s12, v5.s22); rc_pin(v5.rc); rc_pin(v5.kp1); rc_pin(v5.kp2);
       }
       FP_STAMP(17);
-      coop_barrier();   // layer barrier 1
-      // ---------------------------------------------------------- stage 2
-      if (col) {
+      // Stage 2 needs waves B and C's wrenches and wave D's settled reward (it overwrites L.pre) -- not the network's first layer, whose
+      // barrier is 0.4 us further on (its 256 outputs' tanh + split epilogue): the three waves count themselves in, this wave polls
+      // the count and passes layer barrier 1 INSIDE stage 2.  (A wave's LDS operations execute in order: the count lands behind the data.)
+      // (Rows with the accelerometer keep the barrier in front: their stage 2 opens with the reading, and with the barrier behind it
+      // the network waited -- train_LSTM.py's pair at 8192 envs 9.42 against 9.18 us per step; RMA_full at 4096: 5.40 against 5.62.)
+      constexpr bool EARLY = !sens;
+      if (EARLY) {
+        const unsigned want = 3u * (unsigned)(t + 1);
+        int spins = 0;
+        for (; spins < (1 << 20); spins++) {
+          if (*(volatile unsigned int*)&L.ready == want) break;
+          __builtin_amdgcn_s_sleep(1);
+        }
+        if (spins == (1 << 20) && lane == 0) health_count(a, 0);
+      } else {
+        coop_barrier();   // layer barrier 1
+      }
+      asm volatile("" ::: "memory");
+      // ---------------------------------------------------------- stage 2: the solve (a), the integration and what follows it (b)
+      auto stage2a = [&]() {
         {
           Applied<float> ap;
           {
@@ -391,6 +410,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
           acc_last = reading();
           L.acc[lane] = make_float4(acc_last.x, acc_last.y, acc_last.z, 0.f);
         }
+      };
+      auto stage2b = [&]() {
         pend = false;
         Accel<float> im;
         im.ang = cvt<float>(r5.al); im.thdd1 = (float)r5.t1; im.thdd2 = (float)r5.t2;
@@ -423,6 +444,16 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         fp_put_state(L.st, lane, e.s);
         L.info[lane] = make_uint4((tr ? 1u : 0u) | (rst ? 2u : 0u), e.episode, (uint32_t)steps_post, 0u);
         trt[lane] = tr ? 1 : 0;   // the next pass's previous-action gather (read after O)
+      };
+      // layer barrier 1 in the MIDDLE of stage 2 (the solve is behind, the integration ahead): about where the network arrives at it, so
+      // that neither waits long for the other (in front of stage 2 this wave idled 0.4 us; behind it the network would)
+      if (EARLY) {
+        if (col) stage2a();
+        coop_barrier();   // layer barrier 1
+        if (col) stage2b();
+      } else if (col) {
+        stage2a();
+        stage2b();
       }
       // published: wave D starts on the row at once (value, then tag -- a wave's LDS operations execute in order)
       asm volatile("" ::: "memory");
@@ -463,6 +494,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         L.app[3][lane] = make_float4(Rb.m11, Rb.m12, Rb.m20, Rb.m21);
         L.app[4][lane] = make_float4(Rb.m22, 0.f, 0.f, 0.f);
       }
+      if (!sens) __builtin_amdgcn_wave_barrier();
+      if (!sens && lane == 0) __hip_atomic_fetch_add(&L.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // wave A's stage 2 may read them
       coop_barrier();   // layer barrier 1
       coop_barrier();   // layer barrier 2
       coop_barrier();   // layer barrier 3
@@ -487,6 +520,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
         L.ine[2][lane] = make_double2(in.Tq.y, in.Tq.z);
         L.ine[3][lane] = make_double2(in.t1, in.t2);
       }
+      if (!sens) __builtin_amdgcn_wave_barrier();
+      if (!sens && lane == 0) __hip_atomic_fetch_add(&L.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       coop_barrier();   // layer barrier 1
       coop_barrier();   // layer barrier 2
       coop_barrier();   // layer barrier 3
@@ -544,6 +579,8 @@ __global__ __launch_bounds__(FP_THREADS) void k_rollout_fused_pipe(KArgs a, PolA
       FP_STAMP(42);
       if (t > 0) settle(t - 1);
       FP_STAMP(43);
+      if (!sens) __builtin_amdgcn_wave_barrier();
+      if (!sens && lane == 0) __hip_atomic_fetch_add(&L.ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // L.pre is read: wave A's stage 2 may overwrite it
       coop_barrier();   // layer barrier 1
       // s_{t+1}, the flags and (truncated lanes) the state before the reset: as soon as wave A has published them, not a barrier later
       // (wave A never waits for this wave, so the poll ends; it is bounded all the same)
