@@ -109,7 +109,7 @@ __device__ __forceinline__ void pol_outputs(const float* lgt, int ldl, int NL, i
         const float al = __logf(1.0f + __expf(la)) + 1.0f, be = __logf(1.0f + __expf(lb)) + 1.0f;
         if (smp.explore) {
           const float ga = pol_gamma(al, smp, (uint32_t)(env0 + r), 2u * c), gb = pol_gamma(be, smp, (uint32_t)(env0 + r), 2u * c + 1u);
-          x = ga * __builtin_amdgcn_rcpf(ga + gb);
+          x = fminf(ga * __builtin_amdgcn_rcpf(ga + gb), 1.0f);   // (v_rcp_f32 is good to 1 ulp: without the bound 1 + 2^-23 turned up once in 1.3e9 draws)
         } else {
           x = al * __builtin_amdgcn_rcpf(al + be);
         }
